@@ -1,0 +1,194 @@
+/*
+ * mgea.h -- C ABI of the MI355X-native (gfx950) transformer-inference hot path of
+ * RohitMurali18/Music-Generation-Emotion-Adaptive.
+ *
+ * The reference has no FFI / plugin interface: its hot path is reached by plain
+ * Python attribute access from api_cache.py.  This header is therefore the boundary a maintainer
+ * would bind from Python (ctypes stub in INTEGRATION.md); every entry point names the reference
+ * code it replaces.  Conventions:
+ *   - plain pointers and sizes only; every `*_dev` pointer is a device (HBM) pointer owned by the
+ *     caller (in practice a torch.Tensor's data_ptr()) and only borrowed for the call, except the
+ *     weight arena, which must outlive the handle created on it;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises unless stated;
+ *   - every function returns 0 on success or a negative MGEA_E* code; mgea_last_error() gives
+ *     the thread-local message.  No exception crosses this boundary;
+ *   - handles are internally locked: concurrent calls on one handle serialise (the reference's
+ *     endpoint runs in FastAPI's thread pool, api_cache.py:186-187).
+ */
+#ifndef MGEA_H
+#define MGEA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGEA_OK          0
+#define MGEA_EINVAL     -1   /* bad shape / argument (python: ValueError / RuntimeError) */
+#define MGEA_ENOMEM     -2   /* device allocation failed */
+#define MGEA_EHIP       -3   /* a HIP call failed */
+#define MGEA_ECAPACITY  -4   /* batch or context exceeds what the handle reserved */
+#define MGEA_ENODEVICE  -5   /* no gfx950 device visible */
+
+#define MGEA_DTYPE_F32   0   /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define MGEA_DTYPE_BF16  1   /* perf mode: bf16 weights/KV, fp32 accumulate (bf16 MFMA) */
+
+#define MGEA_BLOCK_PRELN_GELU  0  /* api_cache.py:51-74 GPTBlock (KV-cache model, the default) */
+#define MGEA_BLOCK_POSTLN_RELU 1  /* generate_music/generate.py:25-35 nn.TransformerEncoder twin */
+
+#define MGEA_POS_REFERENCE 0 /* pos_emb[:T] per call: every decode step uses row 0 (api_cache.py:99) */
+#define MGEA_POS_ABSOLUTE  1 /* true positions (build-defined extra, parity unpinned) */
+
+#define MGEA_KV_PAGE_TOKENS 64 /* tokens per KV page (one wave64 tile) */
+
+const char* mgea_last_error(void);
+int mgea_version(void);
+/* number of visible HIP devices, or a negative error */
+int mgea_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder: replaces GPTBlock / GPTWithKV / sample_kvcache (api_cache.py:39-106, 159-184).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgea_decoder mgea_decoder;
+
+typedef struct mgea_decoder_config {
+    int32_t vocab;      /* len(tok2id)                        api_cache.py:109 */
+    int32_t seq_len;    /* rows of the position table         api_cache.py:36  */
+    int32_t d_model;    /*                                    api_cache.py:37  */
+    int32_t n_head;     /* reference hard-codes 8             api_cache.py:112 */
+    int32_t n_layer;    /*                                    api_cache.py:31-32 */
+    int32_t d_ff;       /* 4*d_model in the reference         api_cache.py:83  */
+    int32_t max_batch;  /* rows the KV pool is reserved for */
+    int32_t max_ctx;    /* tokens per row the KV pool is reserved for (may exceed seq_len: decode
+                           steps use position row 0, so the cache can outgrow the table) */
+    int32_t dtype;      /* MGEA_DTYPE_* */
+    int32_t block_mode; /* MGEA_BLOCK_* */
+    int32_t pos_mode;   /* MGEA_POS_* */
+    float   ln_eps;     /* 1e-5 (nn.LayerNorm default) */
+} mgea_decoder_config;
+
+/* Sampler: replaces api_cache.py:169-178.  top_k == 1 is the greedy path (exact argmax, ties to
+ * the lowest id); otherwise softmax(logits/temperature + (-1e10 outside top-k)) optionally cut
+ * to the top_p nucleus, then one multinomial draw per row from a Philox4x32-10 stream keyed by
+ * (seed, row, step) -- matches torch.multinomial in distribution only. */
+typedef struct mgea_sampler_config {
+    float    temperature;  /* > 0 */
+    int32_t  top_k;        /* 0 = no top-k cut */
+    float    top_p;        /* <= 0 or >= 1 = no nucleus cut (build-defined; not in the reference) */
+    int32_t  eos_id;       /* -1 = none; a row that draws eos_id stops (api_cache.py:181) */
+    uint64_t seed;
+} mgea_sampler_config;
+
+/* Weight arena: ONE contiguous fp32 device buffer holding every tensor (one RCCL broadcast moves
+ * it).  Canonical tensor order, each tensor 256-byte aligned, torch layouts ([out, in] Linear):
+ *   0 tok_emb [V,C]   1 pos_emb [L,C]
+ *   per layer i (12 tensors, base 2+12*i): ln1_w ln1_b in_proj_w[3C,C] in_proj_b[3C]
+ *       out_proj_w[C,C] out_proj_b ln2_w ln2_b fc1_w[F,C] fc1_b fc2_w[C,F] fc2_b
+ *   then head_w [V,C], head_b [V].
+ * (names after remap_state_dict, api_cache.py:118-134) */
+int mgea_decoder_arena_layout(const mgea_decoder_config* cfg, int64_t* offsets_floats /* [n] or NULL */,
+                              int32_t* n_tensors, int64_t* total_floats);
+
+int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, mgea_decoder** out);
+int mgea_decoder_destroy(mgea_decoder* h);
+
+/* Forget all cached tokens and reserve KV pages for `batch` rows of up to `max_len` tokens. */
+int mgea_decoder_reset(mgea_decoder* h, int32_t batch, int32_t max_len, void* stream);
+
+/* model(idx, past_kv) (api_cache.py:87-106): append T new tokens per row to the cache and run the
+ * NL blocks with every new token attending to the whole cache, no mask.  ids_dev [B,T] int32;
+ * lens_dev [B] int32 or NULL (ragged rows: only the first lens[b] tokens of row b are real; the
+ * rest are ignored and never cached, so each row equals its solo run).  logits_out_dev [B,T,V]
+ * fp32 or NULL (the sampler's prefill discards them, api_cache.py:163). */
+int mgea_decoder_forward(mgea_decoder* h, const int32_t* ids_dev, const int32_t* lens_dev,
+                         int32_t B, int32_t T, float* logits_out_dev, void* stream);
+
+/* One decode step of the sampling loop (api_cache.py:167-179): feed ids_in_dev [B] (NULL = the
+ * ids the previous step/generate produced), sample, write ids_out_dev [B] (NULL allowed) and
+ * optionally the pre-temperature logits [B,V]. */
+int mgea_decoder_step(mgea_decoder* h, const int32_t* ids_in_dev, const mgea_sampler_config* s,
+                      int32_t* ids_out_dev, float* logits_out_dev, void* stream);
+
+/* sample_kvcache (api_cache.py:159-184) for a batch: reset, prefill (logits dropped), then
+ * n_steps decode steps, the first of which re-feeds each row's last prompt token.  The step is
+ * captured once into a hipGraph and replayed.  ids_out_dev [B, n_steps] int32; entries after a
+ * row's EOS are -1.  Host-synchronises only if eos_id >= 0 (to stop early once all rows ended). */
+int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const int32_t* lens_dev,
+                          int32_t B, int32_t Tp, int32_t n_steps, const mgea_sampler_config* s,
+                          int32_t* ids_out_dev, void* stream);
+
+/* Current cached length of each row -> lens_out_dev [B] (device int32). */
+int mgea_decoder_context_lengths(mgea_decoder* h, int32_t* lens_out_dev, void* stream);
+
+/* Per-kernel-class timing for bench.py's roofline leg: with stride n > 0 every n-th decode step of
+ * generate() runs eagerly (not from the graph) with a hipEvent pair around each launch, recorded on
+ * the launch stream; stride 0 switches it off.  profile_read() synchronises, sums the event pairs
+ * into ms_by_class / launches_by_class (classes: 0 gemm, 1 row epilogues, 2 paged attention,
+ * 3 dense attention, 4 logits+argmax / sampler; n_classes >= 5) and clears the records. */
+int mgea_decoder_profile(mgea_decoder* h, int32_t stride);
+int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* launches_by_class,
+                              int32_t n_classes);
+
+/* Statistics of the last generate(): kernels per step, graph replays, splits; for bench/DESIGN. */
+int mgea_decoder_stats(mgea_decoder* h, int64_t* out /* [8] */);
+
+/* ------------------------------------------------------------------------------------------
+ * DistilBERT(+LoRA) classifier forward: replaces the model call inside
+ * emotion_analysis/inference.py:16-20 (transformers DistilBertForSequenceClassification).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgea_bert mgea_bert;
+
+typedef struct mgea_bert_config {
+    int32_t vocab, max_pos, dim, n_heads, n_layers, hidden, num_labels;
+    int32_t max_tokens; /* B*S capacity of the activation workspace */
+    int32_t dtype;      /* MGEA_DTYPE_* */
+    float   ln_eps;     /* 1e-12 */
+} mgea_bert_config;
+
+/* Arena order (fp32, 256-byte aligned): word_emb[V,D] pos_emb[P,D] emb_ln_w emb_ln_b;
+ * per layer (12 tensors): qkv_w[3D,D] (q_lin,k_lin,v_lin rows stacked, LoRA already merged)
+ * qkv_b[3D] out_w[D,D] out_b sa_ln_w sa_ln_b lin1_w[Hd,D] lin1_b lin2_w[D,Hd] lin2_b
+ * out_ln_w out_ln_b; then pre_w[D,D] pre_b cls_w[labels,D] cls_b. */
+int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats, int32_t* n_tensors,
+                           int64_t* total_floats);
+int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_bert** out);
+int mgea_bert_destroy(mgea_bert* h);
+/* ids_dev [B,S] int32, mask_dev [B,S] int32 0/1 or NULL -> logits_out_dev [B,labels] fp32 and/or
+ * argmax_out_dev [B] int32 (either may be NULL). */
+int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
+                      int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
+
+/* W[out,in] += scale * B[out,r] @ A[r,in] in place (peft LoRA fold, W' = W + (alpha/r) B A;
+ * Scripts/finetuneDistillBert.ipynb:787-795). */
+int mgea_lora_merge(float* w_dev, const float* a_dev, const float* b_dev, int32_t out_dim,
+                    int32_t in_dim, int32_t r, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-level entry points (the kernels the engines are built from), exported so the parity
+ * tests can check each kernel against the oracle in isolation.  All fp32, row-major.
+ * ------------------------------------------------------------------------------------------ */
+/* out[M, N] = A[M,K] @ W[N,K]^T, exact-fp32 MFMA, optional split-K (deterministic slab reduce).
+ * K % 32 == 0.  workspace_dev: >= mgea_op_gemm_workspace_floats(M,N,split_k) floats. */
+int64_t mgea_op_gemm_workspace_floats(int32_t M, int32_t N, int32_t split_k);
+int mgea_op_gemm_f32(const float* a_dev, const float* w_dev, const float* bias_dev /* NULL ok */,
+                     float* out_dev, int32_t M, int32_t N, int32_t K, int32_t split_k,
+                     float* workspace_dev, void* stream);
+/* y = LayerNorm(x) over the last dim C (C % 4 == 0, C <= 4096). */
+int mgea_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
+                      int32_t M, int32_t C, float eps, void* stream);
+/* Non-causal attention over a packed qkv buffer [B*T, 3C] (q | k | v, head h at column h*dh);
+ * key validity = (t < lens[b] if lens) && (mask[b,t] != 0 if mask).  out [B*T, C]. */
+int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const int32_t* mask_dev,
+                          float* out_dev, int32_t B, int32_t T, int32_t n_head, int32_t head_dim,
+                          void* stream);
+/* Sampler on a logits matrix [B,V]; step selects the Philox counter.  probs_out_dev [B,V] or NULL
+ * receives the pre-multinomial distribution. */
+int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s,
+                   int64_t step, int32_t* ids_out_dev, float* probs_out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGEA_H */

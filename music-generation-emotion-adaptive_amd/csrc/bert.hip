@@ -1,0 +1,173 @@
+// DistilBERT(+LoRA, pre-merged) sequence-classifier forward behind the C ABI.  Replaces the
+// `model(**inputs).logits` call of emotion_analysis/inference.py:16-20 (third-party
+// transformers DistilBertForSequenceClassification loaded by emotion_analysis/modeling.py:14-21):
+//   LN(word[ids] + pos[:S]) -> 6 x { qkv = h Wqkv^T + b (q_lin|k_lin|v_lin stacked: one GEMM);
+//   softmax(q k^T / sqrt(dh) + key mask) v; h = LN(out_lin(ctx) + h);
+//   h = LN(lin2(gelu_erf(lin1(h))) + h) } -> h[:,0] -> pre_classifier -> ReLU -> classifier.
+// Prefill-only: every contraction is an MFMA GEMM (gemm_f32.hip) or the MFMA flash attention
+// (attn_dense.hip); LayerNorm / bias / GELU / residual live in the slab epilogues (rowops.hip).
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+using namespace mgea;
+
+namespace {
+enum { B_WORD = 0, B_POS, B_ELNW, B_ELNB, B_HEAD0,
+       BL_QKVW = 0, BL_QKVB, BL_OUTW, BL_OUTB, BL_SALNW, BL_SALNB, BL_L1W, BL_L1B, BL_L2W, BL_L2B, BL_OLNW, BL_OLNB,
+       BL_COUNT };
+
+int bert_layout(const mgea_bert_config& c, std::vector<int64_t>* offs, int64_t* total) {
+    const int64_t V = c.vocab, D = c.dim, Hd = c.hidden, P = c.max_pos, NL = c.num_labels;
+    std::vector<int64_t> sizes = {V * D, P * D, D, D};
+    for (int i = 0; i < c.n_layers; ++i) {
+        const int64_t s[BL_COUNT] = {3 * D * D, 3 * D, D * D, D, D, D, Hd * D, Hd, D * Hd, D, D, D};
+        for (int j = 0; j < BL_COUNT; ++j) sizes.push_back(s[j]);
+    }
+    sizes.push_back(D * D);
+    sizes.push_back(D);
+    sizes.push_back(NL * D);
+    sizes.push_back(NL);
+    int64_t o = 0;
+    if (offs) offs->clear();
+    for (int64_t s : sizes) {
+        if (offs) offs->push_back(o);
+        o += round_up(s, 64);
+    }
+    *total = o;
+    return (int)sizes.size();
+}
+
+int validate(const mgea_bert_config* c) {
+    MGEA_REQUIRE(c, MGEA_EINVAL, "bert config is NULL");
+    MGEA_REQUIRE(c->vocab > 0 && c->max_pos > 0 && c->dim > 0 && c->n_heads > 0 && c->n_layers > 0 && c->hidden > 0 &&
+                     c->num_labels > 0 && c->max_tokens > 0,
+                 MGEA_EINVAL, "bert config: non-positive dimension");
+    MGEA_REQUIRE(c->dim % c->n_heads == 0, MGEA_EINVAL, "dim %d not divisible by n_heads %d", c->dim, c->n_heads);
+    const int dh = c->dim / c->n_heads;
+    MGEA_REQUIRE(dh == 32 || dh == 64, MGEA_EINVAL, "head_dim %d not supported (32 or 64)", dh);
+    MGEA_REQUIRE(c->dim % 32 == 0 && c->hidden % 32 == 0 && c->dim <= 4096, MGEA_EINVAL, "dim/hidden must be multiples of 32, dim <= 4096");
+    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32, MGEA_EINVAL, "bert dtype %d not built (f32 only in this build)", c->dtype);
+    return MGEA_OK;
+}
+}  // namespace
+
+struct mgea_bert {
+    mgea_bert_config cfg{};
+    const float* arena = nullptr;
+    std::vector<int64_t> off;
+    std::mutex mu;
+    float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *slabs = nullptr, *pooled = nullptr,
+          *pooled2 = nullptr;
+    int64_t slab_cap = 0;
+    const float* w(int i) const { return arena + off[i]; }
+    const float* lw(int l, int j) const { return arena + off[B_HEAD0 + l * BL_COUNT + j]; }
+    const float* hw(int j) const { return arena + off[B_HEAD0 + cfg.n_layers * BL_COUNT + j]; }
+};
+
+extern "C" {
+
+int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats, int32_t* n_tensors,
+                           int64_t* total_floats) {
+    MGEA_TRY(validate(cfg));
+    std::vector<int64_t> offs;
+    int64_t total = 0;
+    const int n = bert_layout(*cfg, &offs, &total);
+    if (offsets_floats)
+        for (int i = 0; i < n; ++i) offsets_floats[i] = offs[i];
+    if (n_tensors) *n_tensors = n;
+    if (total_floats) *total_floats = total;
+    return MGEA_OK;
+}
+
+int mgea_bert_destroy(mgea_bert* h) {
+    if (!h) return MGEA_OK;
+    (void)hipDeviceSynchronize();
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2};
+    for (void* q : p)
+        if (q) (void)hipFree(q);
+    delete h;
+    return MGEA_OK;
+}
+
+int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_bert** out) {
+    MGEA_TRY(validate(cfg));
+    MGEA_REQUIRE(arena_dev && out, MGEA_EINVAL, "bert_create: NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: the MI355X path has no CPU fallback");
+        return MGEA_ENODEVICE;
+    }
+    mgea_bert* h = new mgea_bert();
+    h->cfg = *cfg;
+    h->arena = arena_dev;
+    int64_t total = 0;
+    bert_layout(*cfg, &h->off, &total);
+    const int64_t M = cfg->max_tokens, D = cfg->dim, Hd = cfg->hidden;
+    const int64_t nmax = (3 * D > Hd ? 3 * D : Hd);
+    // slabs: big-M GEMMs never split K; the two head GEMMs (M = batch <= max_tokens) may
+    int64_t slab = M * slab_ld((int)nmax);
+    const int64_t head = 32 * (int64_t)(M < 64 ? M : 64) * slab_ld((int)D);
+    slab = slab > head ? slab : head;
+    h->slab_cap = slab;
+    bool ok = hipMalloc((void**)&h->h, M * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, M * 3 * D * 4) == hipSuccess &&
+              hipMalloc((void**)&h->ctx, M * D * 4) == hipSuccess && hipMalloc((void**)&h->ffn, M * Hd * 4) == hipSuccess &&
+              hipMalloc((void**)&h->slabs, slab * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
+              hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+    if (!ok) {
+        set_error("bert_create: out of device memory");
+        mgea_bert_destroy(h);
+        return MGEA_ENOMEM;
+    }
+    *out = h;
+    return MGEA_OK;
+}
+
+int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t S,
+                      float* logits_out_dev, int32_t* argmax_out_dev, void* stream) {
+    MGEA_REQUIRE(h && ids_dev, MGEA_EINVAL, "bert_forward: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = h->cfg;
+    MGEA_REQUIRE(B > 0 && S > 0, MGEA_EINVAL, "bert_forward: bad shape B=%d S=%d", B, S);
+    MGEA_REQUIRE(S <= c.max_pos, MGEA_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, c.max_pos);
+    MGEA_REQUIRE((int64_t)B * S <= c.max_tokens, MGEA_ECAPACITY, "B*S = %lld exceeds max_tokens %d", (long long)B * S, c.max_tokens);
+    const int M = B * S, D = c.dim, Hd = c.hidden, NL = c.num_labels, dh = D / c.n_heads;
+    auto gemm = [&](const float* A, int lda, const float* W, int m, int n, int k, int* Sout) -> int {
+        const int s = pick_split_k(m, n, k);
+        MGEA_REQUIRE((int64_t)s * slab_floats(m, n) <= h->slab_cap, MGEA_ECAPACITY, "internal: bert slab workspace too small");
+        const int rc = launch_gemm_f32(A, lda, W, k, h->slabs, m, n, k, s, st);
+        if (rc < 0) return rc;
+        *Sout = rc;
+        return MGEA_OK;
+    };
+    MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
+                                  D, c.vocab, st));
+    int Sk = 1;
+    for (int l = 0; l < c.n_layers; ++l) {
+        MGEA_TRY(gemm(h->h, D, h->lw(l, BL_QKVW), M, 3 * D, D, &Sk));
+        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
+                                 3 * D, M, 3 * D, ACT_NONE, st));
+        MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, st));
+        MGEA_TRY(gemm(h->ctx, D, h->lw(l, BL_OUTW), M, D, D, &Sk));
+        MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->h, nullptr,
+                                    h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, M, D, 1, st));
+        MGEA_TRY(gemm(h->h, D, h->lw(l, BL_L1W), M, Hd, D, &Sk));
+        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, Hd), (int)slab_ld(Hd), h->lw(l, BL_L1B), h->ffn, Hd, M, Hd,
+                                 ACT_GELU, st));
+        MGEA_TRY(gemm(h->ffn, Hd, h->lw(l, BL_L2W), M, D, Hd, &Sk));
+        MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->h, nullptr,
+                                    h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, M, D, 1, st));
+    }
+    // pooled = h[:, 0]  ->  pre_classifier -> ReLU -> classifier
+    MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+    MGEA_TRY(gemm(h->pooled, D, h->hw(0), B, D, D, &Sk));
+    MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->hw(1), h->pooled2, D, B, D, ACT_RELU, st));
+    MGEA_TRY(gemm(h->pooled2, D, h->hw(2), B, NL, D, &Sk));
+    MGEA_TRY(launch_logits_argmax(h->slabs, Sk, slab_floats(B, NL), (int)slab_ld(NL), h->hw(3), logits_out_dev, B, NL,
+                                  argmax_out_dev, st));
+    return MGEA_OK;
+}
+
+}  // extern "C"

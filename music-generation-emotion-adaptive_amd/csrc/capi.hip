@@ -1,0 +1,79 @@
+// C-ABI glue: error string, device probe, LoRA fold and the op-level entry points the parity
+// tests use to check each kernel against the oracle in isolation (include/mgea.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace mgea {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+}  // namespace mgea
+
+using namespace mgea;
+
+extern "C" {
+
+const char* mgea_last_error(void) { return get_error(); }
+int mgea_version(void) { return 100; }
+
+int mgea_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        set_error("hipGetDeviceCount failed: no HIP device visible");
+        return MGEA_ENODEVICE;
+    }
+    return n;
+}
+
+int mgea_lora_merge(float* w_dev, const float* a_dev, const float* b_dev, int32_t out_dim, int32_t in_dim, int32_t r,
+                    float scale, void* stream) {
+    MGEA_REQUIRE(w_dev && a_dev && b_dev && out_dim > 0 && in_dim > 0 && r > 0, MGEA_EINVAL, "lora_merge: bad argument");
+    return launch_lora_merge(w_dev, a_dev, b_dev, out_dim, in_dim, r, scale, (hipStream_t)stream);
+}
+
+int64_t mgea_op_gemm_workspace_floats(int32_t M, int32_t N, int32_t split_k) {
+    if (split_k < 1) split_k = 1;
+    return (int64_t)split_k * slab_floats(M, N);
+}
+
+int mgea_op_gemm_f32(const float* a_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t M,
+                     int32_t N, int32_t K, int32_t split_k, float* workspace_dev, void* stream) {
+    MGEA_REQUIRE(a_dev && w_dev && out_dev && workspace_dev, MGEA_EINVAL, "op_gemm: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (split_k <= 0) split_k = pick_split_k(M, N, K);
+    const int S = launch_gemm_f32(a_dev, K, w_dev, K, workspace_dev, M, N, K, split_k, st);
+    if (S < 0) return S;
+    return launch_bias_act(workspace_dev, S, slab_floats(M, N), (int)slab_ld(N), bias_dev, out_dev, N, M, N, ACT_NONE, st);
+}
+
+int mgea_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int32_t M, int32_t C,
+                      float eps, void* stream) {
+    MGEA_REQUIRE(x_dev && w_dev && b_dev && y_dev, MGEA_EINVAL, "op_layernorm: NULL argument");
+    return launch_layernorm(x_dev, w_dev, b_dev, y_dev, M, C, eps, (hipStream_t)stream);
+}
+
+int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const int32_t* mask_dev, float* out_dev,
+                          int32_t B, int32_t T, int32_t n_head, int32_t head_dim, void* stream) {
+    MGEA_REQUIRE(qkv_dev && out_dev, MGEA_EINVAL, "op_attention: NULL argument");
+    return launch_attn_dense(qkv_dev, lens_dev, mask_dev, out_dev, B, T, n_head, head_dim, (hipStream_t)stream);
+}
+
+int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s, int64_t step,
+                   int32_t* ids_out_dev, float* probs_out_dev, void* stream) {
+    MGEA_REQUIRE(logits_dev && s, MGEA_EINVAL, "op_sample: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->top_k == 1 && ids_out_dev) {
+        MGEA_TRY(launch_logits_argmax(logits_dev, 1, 0, V, nullptr, nullptr, B, V, ids_out_dev, st));
+        if (!probs_out_dev) return MGEA_OK;
+        return launch_sample(logits_dev, B, V, *s, nullptr, step, nullptr, probs_out_dev, st);
+    }
+    return launch_sample(logits_dev, B, V, *s, nullptr, step, ids_out_dev, probs_out_dev, st);
+}
+
+}  // extern "C"

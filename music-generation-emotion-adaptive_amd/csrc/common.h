@@ -1,0 +1,151 @@
+// Shared host/device helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/mgea.h"
+
+namespace mgea {
+
+// ---- error plumbing (thread-local message behind mgea_last_error) --------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define MGEA_CHECK_HIP(expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            ::mgea::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                              __FILE__, __LINE__);                                    \
+            return MGEA_EHIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+#define MGEA_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::mgea::set_error(__VA_ARGS__);      \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define MGEA_TRY(expr)               \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != MGEA_OK) return _rc; \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------
+
+// P[z][M, ldp] = A[M, k-slice z] @ W[N, k-slice z]^T   (raw partial products, no bias)
+// ldp = round_up(N, 64); slab stride = M * ldp floats.  K % 32 == 0.
+int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* P, int M, int N, int K,
+                    int split_k, hipStream_t st);
+// chooses split_k so the grid fills the chip (deterministic function of the shape)
+int pick_split_k(int M, int N, int K);
+static inline int64_t slab_ld(int N) { return round_up(N, 64); }
+static inline int64_t slab_floats(int M, int N) { return (int64_t)M * slab_ld(N); }
+
+// Row epilogues over S slabs P (slab stride `ps`, leading dim `ldp`): v = sum_s P[s][m][n] + bias[n]
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+// out[m, n] = act(v)
+int launch_bias_act(const float* P, int S, int64_t ps, int ldp, const float* bias, float* out, int ldo,
+                    int M, int N, int act, hipStream_t st);
+// pre-LN :  x += v;  xn = LN(x; lnw, lnb) (xn written only if lnw != NULL)
+// post-LN:  x = LN(x + v; lnw, lnb)
+int launch_bias_res_ln(const float* P, int S, int64_t ps, int ldp, const float* bias, float* x, float* xn,
+                       const float* lnw, const float* lnb, float eps, int M, int C, int post_ln,
+                       hipStream_t st);
+int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int C, float eps,
+                     hipStream_t st);
+
+struct KvPool {
+    float* base;          // [n_layer][n_pages][2][H][64*dh]
+    int32_t n_pages;      // physical pages per layer
+    int32_t H, dh;
+    int64_t layer_stride; // floats
+    __host__ __device__ int64_t page_floats() const { return (int64_t)MGEA_KV_PAGE_TOKENS * dh; }
+};
+
+// decoder embedding: x[m] = tok_emb[ids[m]] + pos_emb[pos]; xn = LN(x) if lnw.
+// rows m = b*T + t; rows with t >= lens[b] are zero-filled.  pos = t (+ ctx_len[b] if absolute).
+int launch_embed_ln(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
+                    const float* pos_emb, float* x, float* xn, const float* lnw, const float* lnb, float eps,
+                    int B, int T, int C, int vocab, int pos_rows, int absolute_pos, hipStream_t st);
+// BERT embedding: h[m] = LN(word[ids[m]] + pos[t])
+int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
+                         const float* lnb, float eps, float* h, int B, int S, int D, int vocab,
+                         hipStream_t st);
+// qkv epilogue of the decoder: v = sum P + bias over [M, 3C]; q -> qbuf[m, C] (and k|v -> kvbuf
+// [m, 2C] if kvbuf != NULL, for the no-cache attention); k, v of real tokens -> KV pages of `layer`
+// at position ctx_len[b] + t.
+int launch_qkv_scatter(const float* P, int S, int64_t ps, int ldp, const float* bias, float* qkv_out,
+                       const KvPool& pool, int layer, const int32_t* page_table, int max_pages,
+                       const int32_t* ctx_len, const int32_t* lens, int B, int T, int C, hipStream_t st);
+// decode / extend attention over the paged cache: query rows m = b*T + t attend to
+// ctx_len[b] + (lens ? lens[b] : T) cached tokens.  q read from qkv[m, 0:C] (row stride 3C).
+int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int32_t* page_table,
+                      int max_pages, const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T,
+                      int C, hipStream_t st);
+// dense non-causal attention over the qkv buffer itself (prefill without past, BERT)
+int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T,
+                      int H, int dh, hipStream_t st);
+
+// logits row epilogue: v = sum P + bias; optional store to logits[m, V]; greedy argmax path writes
+// next ids and advances the per-row state (see decoder.hip).
+struct StepState {
+    int32_t* cur_ids;   // [B] token fed to the next step
+    int32_t* ctx_len;   // [B]
+    int32_t* done;      // [B]
+    int32_t* row_step;  // [B] index of the step each row is producing (also the Philox counter)
+    int32_t* n_done;    // [1]
+    int32_t* ids_out;   // [B, n_steps] or NULL
+    int32_t  n_steps;
+    int32_t  eos_id;
+};
+int launch_logits_argmax(const float* P, int S, int64_t ps, int ldp, const float* bias, float* logits,
+                         int M, int V, int32_t* argmax_out, hipStream_t st);
+// sampler over logits [B,V] (top_k != 1); writes ids[b]; probs_out optional
+int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const int32_t* row_step_dev,
+                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st);
+// after ids for this step are in `sampled` [B]: apply EOS/done logic, write ids_out[b, step],
+// cur_ids, ctx_len += 1, row_step += 1
+int launch_advance(const int32_t* sampled, const StepState& s, int B, hipStream_t st);
+// ctx_len[b] += (lens ? lens[b] : T)
+int launch_add_lens(int32_t* ctx_len, const int32_t* lens, int T, int B, hipStream_t st);
+// cur_ids[b] = ids[b, (lens ? lens[b] : T) - 1]
+int launch_take_last(const int32_t* ids, const int32_t* lens, int32_t* cur_ids, int B, int T, hipStream_t st);
+int launch_gather_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int row_step, int C,
+                       hipStream_t st);
+int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int in_dim, int r, float scale,
+                      hipStream_t st);
+
+}  // namespace mgea
+
+// ---- device helpers --------------------------------------------------------------------------
+#ifdef __HIPCC__
+namespace mgea {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+}  // namespace mgea
+#endif

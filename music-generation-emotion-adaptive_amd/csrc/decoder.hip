@@ -1,0 +1,567 @@
+// Decoder engine behind the C ABI: owns the paged KV pool, activation workspace and the captured
+// hipGraph of one decode step.  Replaces GPTWithKV.forward / GPTBlock.forward / sample_kvcache
+// (api_cache.py:51-74, 87-106, 159-184); weight names follow remap_state_dict (api_cache.py:118-134).
+//
+// Reference quirks reproduced on purpose: no attention mask anywhere (prefill is
+// bidirectional), every call adds pos_emb[:T] so decode steps always use position row 0, the
+// prefill logits are dropped and the first decode step re-feeds the last prompt token (which
+// therefore sits in the cache twice).
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+using namespace mgea;
+
+namespace {
+enum { T_TOK = 0, T_POS = 1, L_LN1W = 0, L_LN1B, L_INW, L_INB, L_OUTW, L_OUTB, L_LN2W, L_LN2B, L_FC1W, L_FC1B,
+       L_FC2W, L_FC2B, L_COUNT };
+
+int arena_layout(const mgea_decoder_config& c, std::vector<int64_t>* offs, int64_t* total) {
+    const int64_t V = c.vocab, C = c.d_model, F = c.d_ff, L = c.seq_len;
+    std::vector<int64_t> sizes;
+    sizes.push_back(V * C);
+    sizes.push_back(L * C);
+    for (int i = 0; i < c.n_layer; ++i) {
+        const int64_t s[L_COUNT] = {C, C, 3 * C * C, 3 * C, C * C, C, C, C, F * C, F, C * F, C};
+        for (int j = 0; j < L_COUNT; ++j) sizes.push_back(s[j]);
+    }
+    sizes.push_back(V * C);
+    sizes.push_back(V);
+    int64_t o = 0;
+    if (offs) offs->clear();
+    for (int64_t s : sizes) {
+        if (offs) offs->push_back(o);
+        o += round_up(s, 64);
+    }
+    *total = o;
+    return (int)sizes.size();
+}
+
+int validate(const mgea_decoder_config* c) {
+    MGEA_REQUIRE(c, MGEA_EINVAL, "decoder config is NULL");
+    MGEA_REQUIRE(c->vocab > 0 && c->seq_len > 0 && c->d_model > 0 && c->n_head > 0 && c->n_layer > 0 && c->d_ff > 0,
+                 MGEA_EINVAL, "decoder config: non-positive dimension");
+    MGEA_REQUIRE(c->d_model % c->n_head == 0, MGEA_EINVAL, "d_model %d not divisible by n_head %d", c->d_model, c->n_head);
+    const int dh = c->d_model / c->n_head;
+    MGEA_REQUIRE(dh == 32 || dh == 64, MGEA_EINVAL, "head_dim %d not supported (32 or 64)", dh);
+    MGEA_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, MGEA_EINVAL, "d_model and d_ff must be multiples of 32");
+    MGEA_REQUIRE(c->d_model <= 4096, MGEA_EINVAL, "d_model > 4096 not supported");
+    MGEA_REQUIRE(c->max_batch > 0 && c->max_ctx > 0, MGEA_EINVAL, "max_batch / max_ctx must be positive");
+    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32, MGEA_EINVAL, "decoder dtype %d not built (f32 only in this build)", c->dtype);
+    MGEA_REQUIRE(c->block_mode == MGEA_BLOCK_PRELN_GELU || c->block_mode == MGEA_BLOCK_POSTLN_RELU, MGEA_EINVAL, "bad block_mode");
+    return MGEA_OK;
+}
+}  // namespace
+
+struct mgea_decoder {
+    mgea_decoder_config cfg{};
+    const float* arena = nullptr;
+    std::vector<int64_t> off;
+    int dh = 0;
+    std::mutex mu;
+
+    // KV pool
+    KvPool kv{};
+    int pages_per_row_cap = 0;  // ceil(max_ctx / 64)
+    int max_pages = 0;          // page-table row stride (== pages_per_row_cap)
+    int32_t* page_table = nullptr;
+    // per-row state
+    int32_t *ctx_len = nullptr, *cur_ids = nullptr, *done = nullptr, *row_step = nullptr, *n_done = nullptr,
+            *sampled = nullptr, *ids_hist = nullptr;
+    int ids_hist_stride = 0;
+    // host mirror
+    int cur_batch = 0, reserved_len = 0, host_max_len = 0, host_min_len = 0;
+    // workspace
+    int64_t ws_tokens = 0;
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *slabs = nullptr,
+          *logits = nullptr;
+    int64_t slab_cap = 0;
+    // graph of one decode step
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    int g_batch = -1;
+    mgea_sampler_config g_samp{};
+    int64_t stats[8] = {0};
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
+    int prof_stride = 0;  // 0 = off; n = time every n-th decode step of generate(), run eagerly
+    bool prof_now = false;
+    struct ProfRec { hipEvent_t a, b; int cls; };
+    std::vector<ProfRec> prof;
+
+    const float* w(int idx) const { return arena + off[idx]; }
+    const float* lw(int layer, int j) const { return arena + off[2 + layer * L_COUNT + j]; }
+    const float* head_w() const { return arena + off[2 + cfg.n_layer * L_COUNT]; }
+    const float* head_b() const { return arena + off[3 + cfg.n_layer * L_COUNT]; }
+};
+
+namespace {
+
+enum { PC_GEMM = 0, PC_ROWOP = 1, PC_ATTN_PAGED = 2, PC_ATTN_DENSE = 3, PC_SAMPLE = 4, PC_COUNT = 5 };
+
+struct ProfScope {
+    mgea_decoder* h;
+    hipStream_t st;
+    bool on;
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls;
+    ProfScope(mgea_decoder* h_, int cls_, hipStream_t st_) : h(h_), st(st_), on(h_->prof_now), cls(cls_) {
+        if (on) {
+            on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+            if (on) (void)hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(b, st);
+            h->prof.push_back({a, b, cls});
+        }
+    }
+};
+#define PROF(cls, call)                \
+    do {                               \
+        ProfScope _ps(h, cls, st);     \
+        MGEA_TRY(call);                \
+    } while (0)
+
+void free_ws(mgea_decoder* h) {
+    float** p[] = {&h->x, &h->xn, &h->qkv, &h->att, &h->hbuf, &h->slabs, &h->logits};
+    for (auto q : p) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    h->ws_tokens = 0;
+    h->slab_cap = 0;
+}
+
+void drop_graph(mgea_decoder* h) {
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->gexec = nullptr;
+    h->graph = nullptr;
+    h->g_batch = -1;
+}
+
+int64_t slab_need(const mgea_decoder_config& c, int M) {
+    const int C = c.d_model, F = c.d_ff, V = c.vocab;
+    const int shapes[5][2] = {{3 * C, C}, {C, C}, {F, C}, {C, F}, {V, C}};
+    int64_t need = 0;
+    const int Mh = M > 4096 ? 4096 : M;  // the head runs in row chunks of <= 4096
+    for (int i = 0; i < 5; ++i) {
+        const int m = (i == 4) ? Mh : M;
+        const int64_t s = (int64_t)pick_split_k(m, shapes[i][0], shapes[i][1]) * slab_floats(m, shapes[i][0]);
+        need = s > need ? s : need;
+    }
+    return need;
+}
+
+int ensure_ws(mgea_decoder* h, int64_t M) {
+    if (M <= h->ws_tokens) return MGEA_OK;
+    MGEA_CHECK_HIP(hipDeviceSynchronize());
+    free_ws(h);
+    drop_graph(h);  // captured pointers die with the old workspace
+    const int C = h->cfg.d_model, F = h->cfg.d_ff;
+    int64_t slab = slab_need(h->cfg, (int)M);
+    const int64_t s64 = slab_need(h->cfg, 64);
+    slab = slab > s64 ? slab : s64;
+#define ALLOC(ptr, n)                                                                                   \
+    if (hipMalloc((void**)&(ptr), (size_t)(n) * sizeof(float)) != hipSuccess) {                        \
+        set_error("decoder workspace: out of device memory (%lld floats)", (long long)(n));            \
+        free_ws(h);                                                                                     \
+        return MGEA_ENOMEM;                                                                             \
+    }
+    ALLOC(h->x, M * C);
+    ALLOC(h->xn, M * C);
+    ALLOC(h->qkv, M * 3 * C);
+    ALLOC(h->att, M * C);
+    ALLOC(h->hbuf, M * F);
+    ALLOC(h->slabs, slab);
+    ALLOC(h->logits, (int64_t)h->cfg.max_batch * h->cfg.vocab);
+#undef ALLOC
+    h->slab_cap = slab;
+    h->ws_tokens = M;
+    return MGEA_OK;
+}
+
+// gemm + slab bookkeeping
+int gemm(mgea_decoder* h, const float* A, int lda, const float* W, int M, int N, int K, int* S, hipStream_t st) {
+    const int s = pick_split_k(M, N, K);
+    MGEA_REQUIRE((int64_t)s * slab_floats(M, N) <= h->slab_cap, MGEA_ECAPACITY, "internal: slab workspace too small");
+    ProfScope _ps(h, PC_GEMM, st);
+    const int rc = launch_gemm_f32(A, lda, W, K, h->slabs, M, N, K, s, st);
+    if (rc < 0) return rc;
+    *S = rc;
+    return MGEA_OK;
+}
+
+// The NL blocks over M = B*T rows.  use_cache_attn: attention over the paged cache (decode /
+// extend); otherwise dense attention inside the qkv buffer (prefill with empty cache, twin mode).
+int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cache_attn, bool scatter,
+               hipStream_t st) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, F = c.d_ff, M = B * T;
+    const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
+    for (int l = 0; l < c.n_layer; ++l) {
+        int S = 1;
+        const float* a_in = post ? h->x : h->xn;
+        MGEA_TRY(gemm(h, a_in, C, h->lw(l, L_INW), M, 3 * C, C, &S, st));
+        KvPool kv = h->kv;
+        if (!scatter) kv.base = nullptr;
+        if (scatter) {
+            PROF(PC_ROWOP, launch_qkv_scatter(h->slabs, S, slab_floats(M, 3 * C), (int)slab_ld(3 * C), h->lw(l, L_INB),
+                                        h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, B, T, C, st));
+        } else {
+            PROF(PC_ROWOP, launch_bias_act(h->slabs, S, slab_floats(M, 3 * C), (int)slab_ld(3 * C), h->lw(l, L_INB), h->qkv,
+                                     3 * C, M, 3 * C, ACT_NONE, st));
+        }
+        if (use_cache_attn) {
+            PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T,
+                                       C, st));
+        } else {
+            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, st));
+        }
+        MGEA_TRY(gemm(h, h->att, C, h->lw(l, L_OUTW), M, C, C, &S, st));
+        if (post) {
+            PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_OUTB), h->x,
+                                        nullptr, h->lw(l, L_LN1W), h->lw(l, L_LN1B), c.ln_eps, M, C, 1, st));
+        } else {
+            PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_OUTB), h->x,
+                                        h->xn, h->lw(l, L_LN2W), h->lw(l, L_LN2B), c.ln_eps, M, C, 0, st));
+        }
+        MGEA_TRY(gemm(h, post ? h->x : h->xn, C, h->lw(l, L_FC1W), M, F, C, &S, st));
+        PROF(PC_ROWOP, launch_bias_act(h->slabs, S, slab_floats(M, F), (int)slab_ld(F), h->lw(l, L_FC1B), h->hbuf, F, M, F,
+                                 post ? ACT_RELU : ACT_GELU, st));
+        MGEA_TRY(gemm(h, h->hbuf, F, h->lw(l, L_FC2W), M, C, F, &S, st));
+        if (post) {
+            PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_FC2B), h->x,
+                                        nullptr, h->lw(l, L_LN2W), h->lw(l, L_LN2B), c.ln_eps, M, C, 1, st));
+        } else {
+            const bool last = l + 1 == c.n_layer;
+            PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_FC2B), h->x,
+                                        h->xn, last ? nullptr : h->lw(l + 1, L_LN1W),
+                                        last ? nullptr : h->lw(l + 1, L_LN1B), c.ln_eps, M, C, 0, st));
+        }
+    }
+    return MGEA_OK;
+}
+
+StepState step_state(mgea_decoder* h, int eos) {
+    StepState s;
+    s.cur_ids = h->cur_ids;
+    s.ctx_len = h->ctx_len;
+    s.done = h->done;
+    s.row_step = h->row_step;
+    s.n_done = h->n_done;
+    s.ids_out = h->ids_hist;
+    s.n_steps = h->ids_hist_stride;
+    s.eos_id = eos;
+    return s;
+}
+
+// one decode step on cur_ids (T = 1); logits_out optional
+int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* logits_out, hipStream_t st) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, V = c.vocab;
+    const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
+    PROF(PC_ROWOP, launch_embed_ln(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
+                             post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, 1, C,
+                             V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+    MGEA_TRY(run_blocks(h, B, 1, nullptr, true, true, st));
+    int S = 1;
+    MGEA_TRY(gemm(h, h->x, C, h->head_w(), B, V, C, &S, st));
+    const bool greedy = sc.top_k == 1;
+    float* lg = logits_out ? logits_out : (greedy ? nullptr : h->logits);
+    PROF(PC_SAMPLE, launch_logits_argmax(h->slabs, S, slab_floats(B, V), (int)slab_ld(V), h->head_b(), lg, B, V,
+                                  greedy ? h->sampled : nullptr, st));
+    if (!greedy) PROF(PC_SAMPLE, launch_sample(lg, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
+    PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, sc.eos_id), B, st));
+    return MGEA_OK;
+}
+
+bool same_sampler(const mgea_sampler_config& a, const mgea_sampler_config& b) {
+    return a.temperature == b.temperature && a.top_k == b.top_k && a.top_p == b.top_p && a.eos_id == b.eos_id &&
+           a.seed == b.seed;
+}
+
+int do_reset(mgea_decoder* h, int B, int max_len, hipStream_t st) {
+    const auto& c = h->cfg;
+    MGEA_REQUIRE(B > 0 && B <= c.max_batch, MGEA_ECAPACITY, "batch %d exceeds max_batch %d", B, c.max_batch);
+    MGEA_REQUIRE(max_len > 0 && max_len <= c.max_ctx, MGEA_ECAPACITY, "context %d exceeds max_ctx %d", max_len, c.max_ctx);
+    const int ppr = ceil_div(max_len, MGEA_KV_PAGE_TOKENS);
+    MGEA_REQUIRE((int64_t)B * ppr <= h->kv.n_pages, MGEA_ECAPACITY, "KV pool too small: need %d pages", B * ppr);
+    // page allocation: logical page j of row b -> physical j*B + b (the rows' j-th pages are
+    // neighbours, so a decode step streams one contiguous region per page index)
+    std::vector<int32_t> pt((size_t)c.max_batch * h->max_pages, 0);
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < ppr; ++j) pt[(size_t)b * h->max_pages + j] = j * B + b;
+    MGEA_CHECK_HIP(hipMemcpyAsync(h->page_table, pt.data(), pt.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MGEA_CHECK_HIP(hipStreamSynchronize(st));  // pt is a stack-lifetime host buffer
+    const size_t nb = (size_t)c.max_batch * sizeof(int32_t);
+    MGEA_CHECK_HIP(hipMemsetAsync(h->ctx_len, 0, nb, st));
+    MGEA_CHECK_HIP(hipMemsetAsync(h->cur_ids, 0, nb, st));
+    MGEA_CHECK_HIP(hipMemsetAsync(h->done, 0, nb, st));
+    MGEA_CHECK_HIP(hipMemsetAsync(h->row_step, 0, nb, st));
+    MGEA_CHECK_HIP(hipMemsetAsync(h->n_done, 0, 16, st));
+    h->cur_batch = B;
+    h->reserved_len = ppr * MGEA_KV_PAGE_TOKENS < c.max_ctx ? ppr * MGEA_KV_PAGE_TOKENS : c.max_ctx;
+    h->host_max_len = 0;
+    h->host_min_len = 0;
+    return MGEA_OK;
+}
+
+int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, int T, float* logits_out,
+               hipStream_t st) {
+    const auto& c = h->cfg;
+    MGEA_REQUIRE(ids, MGEA_EINVAL, "forward: ids is NULL");
+    MGEA_REQUIRE(h->cur_batch > 0, MGEA_EINVAL, "forward: call mgea_decoder_reset first");
+    MGEA_REQUIRE(B == h->cur_batch, MGEA_EINVAL, "forward: batch %d differs from the reset batch %d", B, h->cur_batch);
+    MGEA_REQUIRE(T > 0, MGEA_EINVAL, "forward: T must be positive");
+    // the reference fails with a broadcast RuntimeError when T exceeds the position table (api_cache.py:99)
+    MGEA_REQUIRE(T <= c.seq_len, MGEA_EINVAL, "T=%d exceeds the position table (%d rows)", T, c.seq_len);
+    const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
+    if (!post)
+        MGEA_REQUIRE(h->host_max_len + T <= h->reserved_len, MGEA_ECAPACITY,
+                     "context %d + %d new tokens exceeds the reserved %d", h->host_max_len, T, h->reserved_len);
+    const int C = c.d_model, V = c.vocab;
+    const int64_t M = (int64_t)B * T;
+    MGEA_REQUIRE(M < (1ll << 30), MGEA_EINVAL, "forward: too many tokens");
+    MGEA_TRY(ensure_ws(h, M));
+    MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
+                             post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
+                             V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, st));
+    const bool cache_attn = (!post) && h->host_max_len > 0;
+    MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
+    if (logits_out) {
+        for (int64_t r0 = 0; r0 < M; r0 += 4096) {
+            const int rows = (int)((M - r0) < 4096 ? (M - r0) : 4096);
+            int S = 1;
+            MGEA_TRY(gemm(h, h->x + r0 * C, C, h->head_w(), rows, V, C, &S, st));
+            MGEA_TRY(launch_bias_act(h->slabs, S, slab_floats(rows, V), (int)slab_ld(V), h->head_b(),
+                                     logits_out + r0 * V, V, rows, V, ACT_NONE, st));
+        }
+    }
+    if (!post) {
+        MGEA_TRY(launch_add_lens(h->ctx_len, lens, T, B, st));
+        h->host_max_len += T;
+    }
+    MGEA_TRY(launch_take_last(ids, lens, h->cur_ids, B, T, st));
+    return MGEA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgea_decoder_arena_layout(const mgea_decoder_config* cfg, int64_t* offsets_floats, int32_t* n_tensors,
+                              int64_t* total_floats) {
+    MGEA_TRY(validate(cfg));
+    std::vector<int64_t> offs;
+    int64_t total = 0;
+    const int n = arena_layout(*cfg, &offs, &total);
+    if (offsets_floats)
+        for (int i = 0; i < n; ++i) offsets_floats[i] = offs[i];
+    if (n_tensors) *n_tensors = n;
+    if (total_floats) *total_floats = total;
+    return MGEA_OK;
+}
+
+int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, mgea_decoder** out) {
+    MGEA_TRY(validate(cfg));
+    MGEA_REQUIRE(arena_dev && out, MGEA_EINVAL, "decoder_create: NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: the MI355X path has no CPU fallback");
+        return MGEA_ENODEVICE;
+    }
+    mgea_decoder* h = new mgea_decoder();
+    h->cfg = *cfg;
+    h->arena = arena_dev;
+    int64_t total = 0;
+    arena_layout(*cfg, &h->off, &total);
+    h->dh = cfg->d_model / cfg->n_head;
+    h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
+    h->max_pages = h->pages_per_row_cap;
+    h->kv.n_pages = cfg->max_batch * h->pages_per_row_cap;
+    h->kv.H = cfg->n_head;
+    h->kv.dh = h->dh;
+    h->kv.layer_stride = (int64_t)h->kv.n_pages * 2 * cfg->n_head * h->kv.page_floats();
+    const size_t pool_bytes = (size_t)h->kv.layer_stride * cfg->n_layer * sizeof(float);
+    auto fail = [&](int code, const char* what) {
+        set_error("decoder_create: %s", what);
+        mgea_decoder_destroy(h);
+        return code;
+    };
+    if (cfg->block_mode == MGEA_BLOCK_PRELN_GELU) {
+        if (hipMalloc((void**)&h->kv.base, pool_bytes) != hipSuccess) return fail(MGEA_ENOMEM, "KV pool allocation failed");
+        if (hipMemset(h->kv.base, 0, pool_bytes) != hipSuccess) return fail(MGEA_EHIP, "KV pool memset failed");
+    }
+    const size_t nb = (size_t)cfg->max_batch * sizeof(int32_t);
+    h->ids_hist_stride = cfg->max_ctx;
+    if (hipMalloc((void**)&h->page_table, nb * h->max_pages) != hipSuccess || hipMalloc((void**)&h->ctx_len, nb) != hipSuccess ||
+        hipMalloc((void**)&h->cur_ids, nb) != hipSuccess || hipMalloc((void**)&h->done, nb) != hipSuccess ||
+        hipMalloc((void**)&h->row_step, nb) != hipSuccess || hipMalloc((void**)&h->sampled, nb) != hipSuccess ||
+        hipMalloc((void**)&h->n_done, 16) != hipSuccess ||
+        hipMalloc((void**)&h->ids_hist, nb * h->ids_hist_stride) != hipSuccess)
+        return fail(MGEA_ENOMEM, "state allocation failed");
+    (void)hipMemset(h->page_table, 0, nb * h->max_pages);
+    (void)hipMemset(h->ctx_len, 0, nb);
+    (void)hipMemset(h->done, 0, nb);
+    (void)hipMemset(h->row_step, 0, nb);
+    (void)hipMemset(h->cur_ids, 0, nb);
+    (void)hipMemset(h->n_done, 0, 16);
+    const int rc = ensure_ws(h, cfg->max_batch > 64 ? cfg->max_batch : 64);
+    if (rc != MGEA_OK) {
+        mgea_decoder_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return MGEA_OK;
+}
+
+int mgea_decoder_destroy(mgea_decoder* h) {
+    if (!h) return MGEA_OK;
+    (void)hipDeviceSynchronize();
+    drop_graph(h);
+    free_ws(h);
+    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist};
+    for (void* q : p)
+        if (q) (void)hipFree(q);
+    delete h;
+    return MGEA_OK;
+}
+
+int mgea_decoder_reset(mgea_decoder* h, int32_t batch, int32_t max_len, void* stream) {
+    MGEA_REQUIRE(h, MGEA_EINVAL, "decoder handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return do_reset(h, batch, max_len, (hipStream_t)stream);
+}
+
+int mgea_decoder_forward(mgea_decoder* h, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t T,
+                         float* logits_out_dev, void* stream) {
+    MGEA_REQUIRE(h, MGEA_EINVAL, "decoder handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return do_forward(h, ids_dev, lens_dev, B, T, logits_out_dev, (hipStream_t)stream);
+}
+
+int mgea_decoder_step(mgea_decoder* h, const int32_t* ids_in_dev, const mgea_sampler_config* s, int32_t* ids_out_dev,
+                      float* logits_out_dev, void* stream) {
+    MGEA_REQUIRE(h && s, MGEA_EINVAL, "decoder_step: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    MGEA_REQUIRE(h->cfg.block_mode == MGEA_BLOCK_PRELN_GELU, MGEA_EINVAL, "decoder_step needs the KV-cache block mode");
+    MGEA_REQUIRE(h->cur_batch > 0, MGEA_EINVAL, "decoder_step: call reset/forward first");
+    MGEA_REQUIRE(h->host_max_len + 1 <= h->reserved_len, MGEA_ECAPACITY, "context %d + 1 exceeds the reserved %d",
+                 h->host_max_len, h->reserved_len);
+    const int B = h->cur_batch;
+    if (ids_in_dev)
+        MGEA_CHECK_HIP(hipMemcpyAsync(h->cur_ids, ids_in_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    MGEA_TRY(enqueue_step(h, B, *s, logits_out_dev, st));
+    h->host_max_len += 1;
+    if (ids_out_dev)
+        MGEA_CHECK_HIP(hipMemcpyAsync(ids_out_dev, h->sampled, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return MGEA_OK;
+}
+
+int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const int32_t* lens_dev, int32_t B,
+                          int32_t Tp, int32_t n_steps, const mgea_sampler_config* s, int32_t* ids_out_dev,
+                          void* stream) {
+    MGEA_REQUIRE(h && s && prompt_ids_dev && ids_out_dev, MGEA_EINVAL, "decoder_generate: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = h->cfg;
+    MGEA_REQUIRE(c.block_mode == MGEA_BLOCK_PRELN_GELU, MGEA_EINVAL, "decoder_generate needs the KV-cache block mode");
+    MGEA_REQUIRE(n_steps >= 0 && Tp > 0, MGEA_EINVAL, "decoder_generate: bad n_steps / Tp");
+    MGEA_REQUIRE(Tp + n_steps <= c.max_ctx, MGEA_ECAPACITY, "prompt %d + %d steps exceeds max_ctx %d", Tp, n_steps, c.max_ctx);
+    MGEA_REQUIRE(s->temperature > 0.f, MGEA_EINVAL, "temperature must be > 0");
+    MGEA_TRY(do_reset(h, B, Tp + n_steps, st));
+    MGEA_TRY(do_forward(h, prompt_ids_dev, lens_dev, B, Tp, nullptr, st));  // prefill, logits dropped (api_cache.py:163)
+    if (n_steps == 0) return MGEA_OK;
+
+    // capture one decode step (all per-step state lives in device memory, so one graph serves every step)
+    if (!h->gexec || h->g_batch != B || !same_sampler(h->g_samp, *s)) {
+        drop_graph(h);
+        MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step(h, B, *s, nullptr, st);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc != MGEA_OK) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        MGEA_CHECK_HIP(e);
+        h->graph = g;
+        MGEA_CHECK_HIP(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
+        h->g_batch = B;
+        h->g_samp = *s;
+        size_t nn = 0;
+        (void)hipGraphGetNodes(g, nullptr, &nn);
+        h->stats[0] = (int64_t)nn;
+    }
+    int launched = 0;
+    int32_t host_done = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        if (h->prof_stride > 0 && (i % h->prof_stride) == h->prof_stride / 2) {
+            h->prof_now = true;  // this step runs eagerly with HIP events around every launch
+            const int rc = enqueue_step(h, B, *s, nullptr, st);
+            h->prof_now = false;
+            MGEA_TRY(rc);
+        } else {
+            MGEA_CHECK_HIP(hipGraphLaunch(h->gexec, st));
+        }
+        ++launched;
+        if (s->eos_id >= 0 && (i % 16) == 15) {  // stop once every row has drawn EOS (api_cache.py:181)
+            MGEA_CHECK_HIP(hipMemcpyAsync(&host_done, h->n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MGEA_CHECK_HIP(hipStreamSynchronize(st));
+            if (host_done >= B) break;
+        }
+    }
+    h->host_max_len += launched;
+    h->stats[1] = launched;
+    // rows: ids_hist[b, 0:launched]; steps never run are -1
+    MGEA_CHECK_HIP(hipMemsetAsync(ids_out_dev, 0xff, (size_t)B * n_steps * sizeof(int32_t), st));
+    MGEA_CHECK_HIP(hipMemcpy2DAsync(ids_out_dev, (size_t)n_steps * sizeof(int32_t), h->ids_hist,
+                                    (size_t)h->ids_hist_stride * sizeof(int32_t), (size_t)launched * sizeof(int32_t), B,
+                                    hipMemcpyDeviceToDevice, st));
+    return MGEA_OK;
+}
+
+int mgea_decoder_context_lengths(mgea_decoder* h, int32_t* lens_out_dev, void* stream) {
+    MGEA_REQUIRE(h && lens_out_dev, MGEA_EINVAL, "context_lengths: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    MGEA_CHECK_HIP(hipMemcpyAsync(lens_out_dev, h->ctx_len, (size_t)(h->cur_batch > 0 ? h->cur_batch : 0) * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MGEA_OK;
+}
+
+int mgea_decoder_profile(mgea_decoder* h, int32_t stride) {
+    MGEA_REQUIRE(h && stride >= 0, MGEA_EINVAL, "decoder_profile: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->prof_stride = stride;
+    return MGEA_OK;
+}
+
+int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* launches_by_class, int32_t n_classes) {
+    MGEA_REQUIRE(h && ms_by_class && launches_by_class && n_classes >= PC_COUNT, MGEA_EINVAL, "decoder_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    MGEA_CHECK_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < n_classes; ++i) { ms_by_class[i] = 0.0; launches_by_class[i] = 0; }
+    for (auto& r : h->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ms_by_class[r.cls] += ms;
+            launches_by_class[r.cls] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->prof.clear();
+    return MGEA_OK;
+}
+
+int mgea_decoder_stats(mgea_decoder* h, int64_t* out) {
+    MGEA_REQUIRE(h && out, MGEA_EINVAL, "decoder_stats: NULL argument");
+    for (int i = 0; i < 8; ++i) out[i] = h->stats[i];
+    return MGEA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""Thin torch-tensor wrappers over the op-level C entry points (mgea_op_* in include/mgea.h).
+Used by the parity tests to check single kernels; the engines do not go through these."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import SamplerConfig, check, ptr, stream_ptr
+
+
+def _dev(t: torch.Tensor) -> torch.Tensor:
+    if t.device.type != "cuda":
+        raise RuntimeError("mgea ops need ROCm device tensors; there is no CPU path")
+    return t.contiguous()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, split_k: int = 0) -> torch.Tensor:
+    """a [M,K] @ w[N,K]^T (+ bias): exact-fp32 MFMA GEMM with deterministic split-K."""
+    lib = _lib.load()
+    a, w = _dev(a.float()), _dev(w.float())
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {w.shape[1]}x{N})")
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    slabs = split_k if split_k > 0 else (32 if M <= 64 else 1)
+    ws = torch.empty(max(1, lib.mgea_op_gemm_workspace_floats(M, N, slabs)), dtype=torch.float32, device=a.device)
+    b = None if bias is None else _dev(bias.float())
+    check(lib.mgea_op_gemm_f32(ptr(a), ptr(w), ptr(b), ptr(out), M, N, K, split_k, ptr(ws), stream_ptr()))
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = _lib.load()
+    x, w, b = _dev(x.float()), _dev(w.float()), _dev(b.float())
+    M, Cd = x.shape
+    y = torch.empty_like(x)
+    check(lib.mgea_op_layernorm(ptr(x), ptr(w), ptr(b), ptr(y), M, Cd, float(eps), stream_ptr()))
+    return y
+
+
+def attention(qkv: torch.Tensor, n_head: int, lens: Optional[torch.Tensor] = None,
+              mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [B,T,3C] -> [B,T,C]; non-causal, keys valid per lens / mask."""
+    lib = _lib.load()
+    qkv = _dev(qkv.float())
+    B, T, C3 = qkv.shape
+    Cd = C3 // 3
+    out = torch.empty(B, T, Cd, dtype=torch.float32, device=qkv.device)
+    l32 = None if lens is None else _dev(lens.to(torch.int32))
+    m32 = None if mask is None else _dev(mask.to(torch.int32))
+    check(lib.mgea_op_attention_f32(ptr(qkv), ptr(l32), ptr(m32), ptr(out), B, T, n_head, Cd // n_head, stream_ptr()))
+    return out
+
+
+def sample(logits: torch.Tensor, temperature=1.0, top_k=50, top_p=None, seed=0, step=0, want_probs=False):
+    lib = _lib.load()
+    logits = _dev(logits.float())
+    B, V = logits.shape
+    s = SamplerConfig(temperature=float(temperature), top_k=int(top_k) if top_k else 0,
+                      top_p=float(top_p) if top_p else 0.0, eos_id=-1, seed=int(seed))
+    ids = torch.empty(B, dtype=torch.int32, device=logits.device)
+    probs = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_probs else None
+    check(lib.mgea_op_sample(ptr(logits), B, V, C.byref(s), int(step), ptr(ids), ptr(probs), stream_ptr()))
+    return (ids, probs) if want_probs else ids

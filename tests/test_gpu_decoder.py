@@ -1,0 +1,144 @@
+"""Parity of the HIP decoder engine (through the C ABI) against the oracle and the golden vectors
+from the reference's own classes: bit-exact greedy ids, logits within 1e-3 (north_star bar)."""
+import numpy as np
+import pytest
+import torch
+
+from mgea import synth
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3  # BASELINE.json north_star: "logits within 1e-3 fp32"
+
+
+def make(g, max_batch=8, **kw):
+    from mgea.decoder import DecoderEngine
+    seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
+    sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
+    return DecoderEngine(sd, n_head=n_head, max_batch=max_batch, max_ctx=seq_len, **kw), sd, n_head
+
+
+def prompts_of(g):
+    n = sum(1 for k in g.files if k.startswith("prompt"))
+    return [g[f"prompt{i}"].tolist() for i in range(n)]
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny8h"])
+def test_prefill_logits_vs_golden(golden, tag):
+    g = golden("decoder_" + tag)
+    eng, _, _ = make(g)
+    for i, p in enumerate(prompts_of(g)):
+        logits = eng.reset_and_prefill(torch.tensor([p])).cpu()
+        np.testing.assert_allclose(logits[0].numpy(), g[f"prefill_logits{i}"], atol=LOGIT_TOL, rtol=0)
+        assert np.abs(logits[0].numpy() - g[f"prefill_logits{i}"]).max() < 5e-5  # what fp32 actually achieves
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny8h"])
+def test_step_logits_and_greedy_vs_golden(golden, tag):
+    g = golden("decoder_" + tag)
+    eng, _, _ = make(g)
+    samp = eng.sampler(1.0, 1)
+    for i, p in enumerate(prompts_of(g)):
+        eng.reset_and_prefill(torch.tensor([p]), want_logits=False)
+        want = g[f"step_logits{i}"]
+        ids = list(p)
+        for s in range(want.shape[0]):
+            out, lg = eng.step(None, samp, want_logits=True)   # first step re-feeds the last prompt token
+            np.testing.assert_allclose(lg[0].cpu().numpy(), want[s], atol=LOGIT_TOL, rtol=0)
+            ids.append(int(out[0]))
+        assert ids == g[f"greedy{i}"][: len(ids)].tolist()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny8h", "S"])
+def test_generate_greedy_bit_exact_batched_ragged(golden, tag):
+    g = golden("decoder_" + tag)
+    eng, _, _ = make(g)
+    prompts = prompts_of(g)
+    n_steps = len(g["greedy0"]) - len(prompts[0])
+    out = eng.generate(prompts, n_steps, temperature=1.0, top_k=1).cpu()
+    for i, p in enumerate(prompts):
+        assert p + out[i].tolist() == g[f"greedy{i}"].tolist(), f"row {i} diverged from the reference"
+    # replay through the captured graph: identical
+    out2 = eng.generate(prompts, n_steps, temperature=1.0, top_k=1).cpu()
+    assert torch.equal(out, out2)
+    assert eng.stats()["graph_nodes"] > 0
+    lens = eng.context_lengths().cpu().tolist()
+    assert lens == [len(p) + n_steps for p in prompts]   # duplicated last prompt token included
+
+
+def test_generate_vs_oracle_longer_run_crossing_pages(golden):
+    """Decoder-S shape, equal-length prompts, 150 steps (crosses two 64-token KV pages)."""
+    from oracle.decoder_ref import DecoderRef
+    g = golden("decoder_S")
+    eng, sd, n_head = make(g, max_batch=4)
+    ref = DecoderRef(sd, n_head)
+    prompts = prompts_of(g)[:2]
+    n = 150
+    want, sl = ref.generate_greedy(prompts, n, return_logits=True)
+    got = eng.generate(prompts, n, top_k=1).cpu()
+    srt = sl.sort(-1).values
+    gap = (srt[..., -1] - srt[..., -2])
+    for b, p in enumerate(prompts):
+        w = want[b][len(p):]
+        gl = got[b].tolist()
+        if gl != w:   # only acceptable at an fp32 near-tie of the oracle's own top-2 logits
+            first = next(i for i in range(n) if gl[i] != w[i])
+            assert float(gap[b, first]) < 1e-4, f"row {b} diverged at step {first} (gap {float(gap[b, first])})"
+
+
+def test_extend_with_past_multi_token(golden):
+    """model(idx, past) with T > 1 and a non-empty cache (api_cache.py:87-106 semantics)."""
+    from oracle.decoder_ref import DecoderRef
+    g = golden("decoder_tiny")
+    eng, sd, n_head = make(g)
+    ref = DecoderRef(sd, n_head)
+    a, b = torch.tensor([[1, 5, 14, 20]]), torch.tensor([[7, 9, 33]])
+    _, cache, valid = ref.forward(a)
+    want, _, _ = ref.forward(b, cache, valid)
+    eng.reset_and_prefill(a, want_logits=False)
+    got = eng.forward(b).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=LOGIT_TOL, rtol=0)
+
+
+def test_errors_match_reference_classes(golden):
+    g = golden("decoder_tiny")
+    eng, _, _ = make(g, max_batch=2)
+    with pytest.raises(RuntimeError):          # T > position table: broadcast RuntimeError in the reference
+        eng.reset_and_prefill(torch.zeros(1, eng.seq_len + 1, dtype=torch.long))
+    with pytest.raises(IndexError):            # id outside the vocabulary: nn.Embedding IndexError
+        eng.reset_and_prefill(torch.tensor([[eng.vocab]]))
+    with pytest.raises(ValueError):            # capacity (new surface)
+        eng.generate([[1, 2]] * 3, 4, top_k=1)
+
+
+def test_eos_stops_rows_independently(golden):
+    g = golden("decoder_tiny")
+    eng, _, _ = make(g)
+    prompts = prompts_of(g)
+    greedy = [g[f"greedy{i}"].tolist() for i in range(len(prompts))]
+    eos = greedy[0][len(prompts[0]) + 3]       # row 0's 4th generated token
+    out = eng.generate(prompts, 20, top_k=1, eos_id=eos).cpu()
+    for i, p in enumerate(prompts):
+        gen = greedy[i][len(p): len(p) + 20]
+        stop = gen.index(eos) + 1 if eos in gen else 20
+        assert out[i, :stop].tolist() == gen[:stop]
+        assert (out[i, stop:] == -1).all()
+
+
+def test_twin_mode_post_ln_relu(golden):
+    """generate_music/generate.py semantics (post-LN, ReLU, no cache) behind the same engine."""
+    g = golden("decoder_tiny")
+    eng, _, _ = make(g, block_mode="twin")
+    p = prompts_of(g)[1]
+    logits = eng.reset_and_prefill(torch.tensor([p])).cpu()
+    np.testing.assert_allclose(logits[0].numpy(), g["twin_logits1"], atol=LOGIT_TOL, rtol=0)
+
+
+def test_topk_sampling_stays_in_topk(golden):
+    g = golden("decoder_tiny")
+    eng, _, _ = make(g)
+    prompts = prompts_of(g)[:1]
+    a = eng.generate(prompts, 12, temperature=1.0, top_k=50, seed=7).cpu()
+    b = eng.generate(prompts, 12, temperature=1.0, top_k=50, seed=7).cpu()
+    c = eng.generate(prompts, 12, temperature=1.0, top_k=50, seed=8).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert int(a.min()) >= 0 and int(a.max()) < eng.vocab
