@@ -51,11 +51,21 @@ def parse():
     return ap.parse_args()
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may run on, capped at the GPU box's
+    per-GPU CPU share (16) -- oversubscribing a 256-core host from a 16-core share is slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("MGEA_CPU_THREADS", "16"))))
+
+
 def cpu_baseline_decoder(sd, prompts, budget_s):
     """Oracle (CPU port of api_cache.py semantics with a projected-KV cache) on the same prompts;
     bounded sample: decode steps until ~budget_s of CPU work."""
     from oracle.decoder_ref import DecoderRef
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     ref = DecoderRef(sd, n_head=N_HEAD)
     idx = torch.tensor(prompts)
     B = idx.shape[0]

@@ -125,6 +125,34 @@ int launch_gather_rows(const float* src, int ld_src, float* dst, int ld_dst, int
 int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int in_dim, int r, float scale,
                       hipStream_t st);
 
+// ---- fused skinny GEMM (decode step, M <= 64): gemm_skinny.hip --------------------------------
+enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
+
+struct SkinnyArgs {
+    const float* A; int lda;
+    const float* W;            // [N, K]
+    const float* bias;         // [N] or NULL
+    int M, N, K;
+    // LN prologue (lnw != NULL): per-row partial stats [64][n_part][2], each over `part_cnt` elements
+    const float* lnw; const float* lnb; float eps;
+    const float* stats_in; int n_part; int part_cnt;
+    // outputs
+    float* out; int ldo;       // QKV: qkv_out [M, N]; RES: x [M, N] (in place); ACT: out [M, ldo]; LOGITS: logits or NULL
+    float* stats_out;          // RES: [64][N/16][2]
+    int act;
+    // QKV scatter
+    KvPool pool; int layer; const int32_t* page_table; int max_pages; const int32_t* ctx_len;
+    const int32_t* lens; int T; int C;
+    // LOGITS
+    float* pmax_val; int32_t* pmax_idx;   // [64][n_tiles]
+};
+int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
+int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
+                       const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
+                       int absolute_pos, hipStream_t st);
+int launch_argmax_advance(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
+                          int B, hipStream_t st);
+
 }  // namespace mgea
 
 // ---- device helpers --------------------------------------------------------------------------

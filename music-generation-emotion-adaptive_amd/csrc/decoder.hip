@@ -6,6 +6,8 @@
 // bidirectional), every call adds pos_emb[:T] so decode steps always use position row 0, the
 // prefill logits are dropped and the first decode step re-feeds the last prompt token (which
 // therefore sits in the cache twice).
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -75,14 +77,16 @@ struct mgea_decoder {
     // workspace
     int64_t ws_tokens = 0;
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *slabs = nullptr,
-          *logits = nullptr;
+          *logits = nullptr, *stats = nullptr, *pmax_val = nullptr;
+    int32_t* pmax_idx = nullptr;
+    bool force_unfused = false;  // MGEA_DECODER_UNFUSED=1: keep the 9-launch-per-layer path (A/B and fallback)
     int64_t slab_cap = 0;
     // graph of one decode step
     hipGraphExec_t gexec = nullptr;
     hipGraph_t graph = nullptr;
     int g_batch = -1;
     mgea_sampler_config g_samp{};
-    int64_t stats[8] = {0};
+    int64_t counters[8] = {0};
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_stride = 0;  // 0 = off; n = time every n-th decode step of generate(), run eagerly
     bool prof_now = false;
@@ -125,7 +129,9 @@ struct ProfScope {
     } while (0)
 
 void free_ws(mgea_decoder* h) {
-    float** p[] = {&h->x, &h->xn, &h->qkv, &h->att, &h->hbuf, &h->slabs, &h->logits};
+    float** p[] = {&h->x, &h->xn, &h->qkv, &h->att, &h->hbuf, &h->slabs, &h->logits, &h->stats, &h->pmax_val};
+    if (h->pmax_idx) (void)hipFree(h->pmax_idx);
+    h->pmax_idx = nullptr;
     for (auto q : p) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -177,6 +183,13 @@ int ensure_ws(mgea_decoder* h, int64_t M) {
     ALLOC(h->hbuf, M * F);
     ALLOC(h->slabs, slab);
     ALLOC(h->logits, (int64_t)h->cfg.max_batch * h->cfg.vocab);
+    ALLOC(h->stats, (int64_t)64 * (C / 16 + 1) * 2);
+    ALLOC(h->pmax_val, (int64_t)64 * ceil_div(h->cfg.vocab, 16));
+    if (hipMalloc((void**)&h->pmax_idx, (size_t)64 * ceil_div(h->cfg.vocab, 16) * sizeof(int32_t)) != hipSuccess) {
+        set_error("decoder workspace: out of device memory");
+        free_ws(h);
+        return MGEA_ENOMEM;
+    }
 #undef ALLOC
     h->slab_cap = slab;
     h->ws_tokens = M;
@@ -245,6 +258,55 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
     return MGEA_OK;
 }
 
+// Fused path for M = B*T <= 64 rows in the KV-cache block mode: 5 launches per layer
+// (gemm_skinny.hip); x carries per-row LayerNorm partial statistics between kernels.
+bool fused_ok(const mgea_decoder* h, int M) {
+    return h->cfg.block_mode == MGEA_BLOCK_PRELN_GELU && M <= 64 && (h->cfg.d_model % 128) == 0 && !h->force_unfused;
+}
+
+int run_blocks_fused(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, F = c.d_ff, M = B * T;
+    int n_part = 1, part_cnt = C;  // the embedding kernel leaves one whole-row partial
+    for (int l = 0; l < c.n_layer; ++l) {
+        SkinnyArgs a{};
+        a.M = M; a.eps = c.ln_eps;
+        // ln1 + in_proj + KV append
+        a.A = h->x; a.lda = C; a.W = h->lw(l, L_INW); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
+        a.lnw = h->lw(l, L_LN1W); a.lnb = h->lw(l, L_LN1B); a.stats_in = h->stats; a.n_part = n_part; a.part_cnt = part_cnt;
+        a.out = h->qkv; a.ldo = 3 * C;
+        a.pool = h->kv; a.layer = l; a.page_table = h->page_table; a.max_pages = h->max_pages; a.ctx_len = h->ctx_len;
+        a.lens = lens; a.T = T; a.C = C;
+        PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
+        if (use_cache_attn) {
+            PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T, C, st));
+        } else {
+            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, st));
+        }
+        // out_proj + residual (+ stats for ln2)
+        SkinnyArgs o{};
+        o.M = M; o.eps = c.ln_eps;
+        o.A = h->att; o.lda = C; o.W = h->lw(l, L_OUTW); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
+        o.out = h->x; o.ldo = C; o.stats_out = h->stats;
+        PROF(PC_GEMM, launch_skinny(EPI_RES, o, st));
+        n_part = C / 16; part_cnt = 16;
+        // ln2 + mlp.0 + GELU
+        SkinnyArgs f{};
+        f.M = M; f.eps = c.ln_eps;
+        f.A = h->x; f.lda = C; f.W = h->lw(l, L_FC1W); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
+        f.lnw = h->lw(l, L_LN2W); f.lnb = h->lw(l, L_LN2B); f.stats_in = h->stats; f.n_part = n_part; f.part_cnt = part_cnt;
+        f.out = h->hbuf; f.ldo = F; f.act = ACT_GELU;
+        PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
+        // mlp.2 + residual (+ stats for the next ln1)
+        SkinnyArgs r{};
+        r.M = M; r.eps = c.ln_eps;
+        r.A = h->hbuf; r.lda = F; r.W = h->lw(l, L_FC2W); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
+        r.out = h->x; r.ldo = C; r.stats_out = h->stats;
+        PROF(PC_GEMM, launch_skinny(EPI_RES, r, st));
+    }
+    return MGEA_OK;
+}
+
 StepState step_state(mgea_decoder* h, int eos) {
     StepState s;
     s.cur_ids = h->cur_ids;
@@ -263,13 +325,32 @@ int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* l
     const auto& c = h->cfg;
     const int C = c.d_model, V = c.vocab;
     const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
+    const bool greedy = sc.top_k == 1;
+    if (fused_ok(h, B)) {
+        // 33 launches: embed, 6 x (qkv, attention, out-proj, fc1, fc2), head (+ per-tile argmax), finalize
+        PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1,
+                                          C, V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+        MGEA_TRY(run_blocks_fused(h, B, 1, nullptr, true, st));
+        SkinnyArgs a{};
+        a.M = B; a.A = h->x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
+        a.out = logits_out ? logits_out : (greedy ? nullptr : h->logits);
+        a.ldo = V; a.pmax_val = h->pmax_val; a.pmax_idx = h->pmax_idx;
+        PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
+        if (greedy) {
+            PROF(PC_SAMPLE, launch_argmax_advance(h->pmax_val, h->pmax_idx, ceil_div(V, 16), step_state(h, sc.eos_id),
+                                                  h->sampled, B, st));
+        } else {
+            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
+            PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, sc.eos_id), B, st));
+        }
+        return MGEA_OK;
+    }
     PROF(PC_ROWOP, launch_embed_ln(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                              post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, 1, C,
                              V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
     MGEA_TRY(run_blocks(h, B, 1, nullptr, true, true, st));
     int S = 1;
     MGEA_TRY(gemm(h, h->x, C, h->head_w(), B, V, C, &S, st));
-    const bool greedy = sc.top_k == 1;
     float* lg = logits_out ? logits_out : (greedy ? nullptr : h->logits);
     PROF(PC_SAMPLE, launch_logits_argmax(h->slabs, S, slab_floats(B, V), (int)slab_ld(V), h->head_b(), lg, B, V,
                                   greedy ? h->sampled : nullptr, st));
@@ -326,11 +407,17 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     const int64_t M = (int64_t)B * T;
     MGEA_REQUIRE(M < (1ll << 30), MGEA_EINVAL, "forward: too many tokens");
     MGEA_TRY(ensure_ws(h, M));
-    MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
-                             post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
-                             V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, st));
     const bool cache_attn = (!post) && h->host_max_len > 0;
-    MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
+    if (fused_ok(h, (int)M)) {
+        MGEA_TRY(launch_embed_stats(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, T, C, V,
+                                    c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+        MGEA_TRY(run_blocks_fused(h, B, T, lens, cache_attn, st));
+    } else {
+        MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
+                                 post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
+                                 V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, st));
+        MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
+    }
     if (logits_out) {
         for (int64_t r0 = 0; r0 < M; r0 += 4096) {
             const int rows = (int)((M - r0) < 4096 ? (M - r0) : 4096);
@@ -379,6 +466,10 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     int64_t total = 0;
     arena_layout(*cfg, &h->off, &total);
     h->dh = cfg->d_model / cfg->n_head;
+    {
+        const char* e = getenv("MGEA_DECODER_UNFUSED");
+        h->force_unfused = e && e[0] == '1';
+    }
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
     h->kv.n_pages = cfg->max_batch * h->pages_per_row_cap;
@@ -495,7 +586,7 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
         h->g_samp = *s;
         size_t nn = 0;
         (void)hipGraphGetNodes(g, nullptr, &nn);
-        h->stats[0] = (int64_t)nn;
+        h->counters[0] = (int64_t)nn;
     }
     int launched = 0;
     int32_t host_done = 0;
@@ -516,7 +607,7 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
         }
     }
     h->host_max_len += launched;
-    h->stats[1] = launched;
+    h->counters[1] = launched;
     // rows: ids_hist[b, 0:launched]; steps never run are -1
     MGEA_CHECK_HIP(hipMemsetAsync(ids_out_dev, 0xff, (size_t)B * n_steps * sizeof(int32_t), st));
     MGEA_CHECK_HIP(hipMemcpy2DAsync(ids_out_dev, (size_t)n_steps * sizeof(int32_t), h->ids_hist,
@@ -560,7 +651,7 @@ int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* lau
 
 int mgea_decoder_stats(mgea_decoder* h, int64_t* out) {
     MGEA_REQUIRE(h && out, MGEA_EINVAL, "decoder_stats: NULL argument");
-    for (int i = 0; i < 8; ++i) out[i] = h->stats[i];
+    for (int i = 0; i < 8; ++i) out[i] = h->counters[i];
     return MGEA_OK;
 }
 

@@ -1,0 +1,366 @@
+// Fused skinny GEMM for the decode step (M <= 64 rows): out[M, N] = f(LN?(A)[M, K] @ W[N, K]^T + bias)
+// with the whole row epilogue inside the kernel, so a decoder layer is 5 launches
+// (QKV, attention, out-proj, FC1, FC2) instead of 9 and no split-K slab ever goes to HBM.
+//
+// Reference ops covered (api_cache.py): ln1 + in_proj + cache append (:60-67), out_proj + residual
+// (:68,72), ln2 + mlp.0 + GELU (:73), mlp.2 + residual (:73), head (:105) + greedy argmax.
+//
+// Decomposition (gfx950): one workgroup = ALL 64 rows x 16 output columns; its NW waves split K
+// (wave w owns k in [w*K/NW, (w+1)*K/NW)), each streaming its W slice straight from HBM into
+// registers (weights are read exactly once per step, 32 contiguous bytes per lane, full 128-B
+// lines per row) and its A slice from L2; products are v_mfma_f32_16x16x4_f32 (exact fp32) issued
+// "swapped" so a lane owns 4 consecutive output columns.  The NW partial tiles are summed through
+// LDS in wave order (deterministic), then 256 threads run the epilogue on float4s.
+//   * LN prologue: the PRODUCER of x (embedding or a residual epilogue) leaves per-row partial
+//     statistics (mean, M2) per 16-column tile; the consumer merges them with Chan's formula
+//     (16 KB instead of re-reading 128 KB of x) and normalises A fragments in registers.
+//   * k order inside the MFMA chain is a fixed permutation (k = k0 + 8g + 4h + s) applied to both
+//     operands; results are run-to-run bit-identical.
+#include "common.h"
+
+namespace mgea {
+
+template <int EPI, bool LN>
+__global__ __launch_bounds__(LN ? 256 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][64][16] (+ 128 floats of LN stats)
+    float* s_mean = red + (blockDim.x >> 6) * 64 * 16;             // all LDS in ONE array (16-B aligned carve)
+    float* s_rstd = s_mean + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kw = a.K / NW, kbeg = wave * kw;
+    const int nchunk = kw >> 5;
+
+    if (LN) {
+        // merge the producer's per-tile (mean, M2) partials: thread t -> row t>>2, partials q, q+4, ...
+        if (tid < 256) {
+            const int row = tid >> 2, q = tid & 3;
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            if (row < a.M) {
+                const float* sp = a.stats_in + ((int64_t)row * a.n_part) * 2;
+                const float cnt = (float)a.part_cnt;
+                for (int p = q; p < a.n_part; p += 4) {
+                    const float2 s = *reinterpret_cast<const float2*>(sp + 2 * p);
+                    const float nn = n + cnt, d = s.x - mean;
+                    mean += d * (cnt / nn);
+                    m2 += s.y + d * d * (n * cnt / nn);
+                    n = nn;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64), m22 = __shfl_xor(m2, o, 64);
+                const float nn = n + n2;
+                if (nn > 0.f) {
+                    const float d = mean2 - mean;
+                    mean += d * (n2 / nn);
+                    m2 += m22 + d * d * (n * n2 / nn);
+                }
+                n = nn;
+            }
+            if (q == 0) {
+                s_mean[row] = mean;
+                s_rstd[row] = (n > 0.f) ? 1.0f / sqrtf(m2 / n + a.eps) : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+
+    // rows of this lane's A fragments (clamped: rows >= M compute garbage that is never stored)
+    const float* arow[4];
+    float mu[4], rs[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int r = mt * 16 + c;
+        if (LN) { mu[mt] = s_mean[r]; rs[mt] = s_rstd[r]; }
+        r = r < a.M ? r : a.M - 1;
+        arow[mt] = a.A + (int64_t)r * a.lda + kbeg + 8 * g;
+    }
+    int wr = n0 + c;
+    wr = wr < a.N ? wr : a.N - 1;
+    const float* wrow = a.W + (int64_t)wr * a.K + kbeg + 8 * g;
+    const float* gptr = a.lnw + kbeg + 8 * g;
+    const float* bptr = a.lnb + kbeg + 8 * g;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 wf[2][2], af[2][4][2], gf[2][2], bf[2][2];
+    auto load_chunk = [&](int buf, int ch) {
+        const int ko = ch * 32;
+        wf[buf][0] = ld4(wrow + ko);
+        wf[buf][1] = ld4(wrow + ko + 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            af[buf][mt][0] = ld4(arow[mt] + ko);
+            af[buf][mt][1] = ld4(arow[mt] + ko + 4);
+        }
+        if (LN) {
+            gf[buf][0] = ld4(gptr + ko); gf[buf][1] = ld4(gptr + ko + 4);
+            bf[buf][0] = ld4(bptr + ko); bf[buf][1] = ld4(bptr + ko + 4);
+        }
+    };
+    auto compute_chunk = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 w4 = wf[buf][h];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float4 x = af[buf][mt][h];
+                if (LN) {
+                    const float4 gg = gf[buf][h], bb = bf[buf][h];
+                    x.x = (x.x - mu[mt]) * rs[mt] * gg.x + bb.x;
+                    x.y = (x.y - mu[mt]) * rs[mt] * gg.y + bb.y;
+                    x.z = (x.z - mu[mt]) * rs[mt] * gg.z + bb.z;
+                    x.w = (x.w - mu[mt]) * rs[mt] * gg.w + bb.w;
+                }
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x.x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x.y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x.z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x.w, acc[mt], 0, 0, 0);
+            }
+        }
+    };
+    load_chunk(0, 0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        if (ch + 1 < nchunk) load_chunk(1, ch + 1);
+        compute_chunk(0);
+        if (ch + 1 < nchunk) {
+            if (ch + 2 < nchunk) load_chunk(0, ch + 2);
+            compute_chunk(1);
+        }
+    }
+
+    // partial tile of this wave -> LDS: D[i = column 4g + r][j = row c]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+        *reinterpret_cast<float4*>(&red[((wave * 64) + mt * 16 + c) * 16 + 4 * g]) =
+            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    __syncthreads();
+
+    // epilogue: thread t -> row t >> 2, columns n0 + 4*(t & 3) .. +3
+    for (int t = tid; t < 256; t += blockDim.x) {
+        const int row = t >> 2, q = t & 3;
+        const int n = n0 + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(&red[row * 16 + 4 * q]);
+        for (int w = 1; w < NW; ++w) v = add4(v, *reinterpret_cast<const float4*>(&red[(w * 64 + row) * 16 + 4 * q]));
+        const bool row_ok = row < a.M;
+        if (EPI != EPI_LOGITS) {
+            // N % 16 == 0 for these epilogues (checked on the host)
+            if (a.bias) v = add4(v, ld4(a.bias + n));
+        }
+        if (EPI == EPI_ACT) {
+            if (a.act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            if (a.act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (row_ok) st4(a.out + (int64_t)row * a.ldo + n, v);
+        }
+        if (EPI == EPI_RES) {
+            float* xp = a.out + (int64_t)row * a.ldo + n;
+            if (row_ok) {
+                v = add4(v, ld4(xp));
+                st4(xp, v);
+            }
+            // (mean, M2) of this row over the tile's 16 columns, for the next LayerNorm
+            float s = (v.x + v.y) + (v.z + v.w);
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            const float mean = s * (1.0f / 16.0f);
+            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+            float m2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            m2 += __shfl_xor(m2, 1, 64);
+            m2 += __shfl_xor(m2, 2, 64);
+            if (q == 0 && row_ok && a.stats_out)
+                *reinterpret_cast<float2*>(a.stats_out + ((int64_t)row * (a.N >> 4) + blockIdx.x) * 2) = make_float2(mean, m2);
+        }
+        if (EPI == EPI_QKV) {
+            const int b = row_ok ? row / a.T : 0, tt = row_ok ? row % a.T : 0;
+            const bool real = row_ok && (a.lens ? (tt < a.lens[b]) : true);
+            if (!real) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok) st4(a.out + (int64_t)row * a.ldo + n, v);
+            if (real && n >= a.C) {
+                const int pos = a.ctx_len[b] + tt;
+                const int page = pos >> 6, slot = pos & 63;
+                if (page < a.max_pages) {
+                    const int phys = a.page_table[b * a.max_pages + page];
+                    const int64_t pf = a.pool.page_floats();
+                    const int isv = n >= 2 * a.C;
+                    const int nn = n - (isv ? 2 * a.C : a.C);
+                    const int hh = nn / a.pool.dh, d = nn % a.pool.dh;
+                    float* page_p = a.pool.base + a.layer * a.pool.layer_stride +
+                                    ((int64_t)(phys * 2 + isv) * a.pool.H + hh) * pf;
+                    if (isv) st4(page_p + slot * a.pool.dh + d, v);
+                    else     st4(page_p + ((d >> 2) * MGEA_KV_PAGE_TOKENS + slot) * 4, v);
+                }
+            }
+        }
+        if (EPI == EPI_LOGITS) {
+            float e[4] = {v.x, v.y, v.z, v.w};
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j < a.N) {
+                    e[j] += a.bias ? a.bias[n + j] : 0.f;
+                    if (row_ok && a.out) a.out[(int64_t)row * a.ldo + n + j] = e[j];
+                    if (e[j] > best) { best = e[j]; bi = n + j; }
+                }
+            }
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (q == 0 && row_ok && a.pmax_val) {
+                a.pmax_val[(int64_t)row * gridDim.x + blockIdx.x] = best;
+                a.pmax_idx[(int64_t)row * gridDim.x + blockIdx.x] = bi;
+            }
+        }
+    }
+}
+
+static int pick_waves(int K, bool ln) {
+    if (ln) return 4;  // the LN merge uses exactly 256 threads
+    for (int nw = 16; nw >= 1; --nw)
+        if (K % (32 * nw) == 0 && K / nw >= 128) return nw;
+    for (int nw = 16; nw >= 1; --nw)
+        if (K % (32 * nw) == 0) return nw;
+    return 1;
+}
+
+template <int EPI>
+static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
+    const bool ln = a.lnw != nullptr;
+    const int nw = pick_waves(a.K, ln);
+    MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
+    MGEA_REQUIRE(a.K % (32 * nw) == 0 && (a.lda % 4) == 0, MGEA_EINVAL, "skinny gemm: K=%d not divisible by %d", a.K, 32 * nw);
+    MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
+    dim3 grid(ceil_div(a.N, 16)), block(64 * nw);
+    const size_t shmem = ((size_t)nw * 64 * 16 + (ln ? 128 : 0)) * sizeof(float);
+    if (ln) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), grid, block, shmem, st, a);
+    else    hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false>), grid, block, shmem, st, a);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
+    switch (epi) {
+        case EPI_QKV: return launch_skinny_t<EPI_QKV>(a, st);
+        case EPI_RES: return launch_skinny_t<EPI_RES>(a, st);
+        case EPI_ACT: return launch_skinny_t<EPI_ACT>(a, st);
+        case EPI_LOGITS: return launch_skinny_t<EPI_LOGITS>(a, st);
+    }
+    set_error("skinny gemm: bad epilogue %d", epi);
+    return MGEA_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------
+// x[m] = tok_emb[ids[m]] + pos_emb[pos]; stats[m] = (mean, M2) of the row (one partial)
+__global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
+                                                         const int32_t* __restrict__ ctx_len,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb, float* __restrict__ x,
+                                                         float* __restrict__ stats, int T, int C, int vocab,
+                                                         int pos_rows, int absolute_pos) {
+    __shared__ float redv[4];
+    const int64_t m = blockIdx.x;
+    const int b = (int)(m / T), t = (int)(m % T);
+    const int nf4 = C >> 2;
+    const bool real = lens ? (t < lens[b]) : true;
+    int id = ids[m];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pos = t + ((absolute_pos && ctx_len) ? ctx_len[b] : 0);
+    pos = pos < pos_rows ? pos : pos_rows - 1;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + i * 256;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nf4) {
+            if (real) v[i] = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
+            st4(x + m * C + f * 4, v[i]);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    auto bsum = [&](float val) {
+        val = wave_sum(val);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) redv[threadIdx.x >> 6] = val;
+        __syncthreads();
+        return (redv[0] + redv[1]) + (redv[2] + redv[3]);
+    };
+    const float mean = bsum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + i * 256;
+        if (f < nf4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float m2 = bsum(q);
+    if (threadIdx.x == 0) *reinterpret_cast<float2*>(stats + m * 2) = make_float2(mean, m2);
+}
+
+int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
+                       const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
+                       int absolute_pos, hipStream_t st) {
+    MGEA_REQUIRE(C % 4 == 0 && C <= 4096, MGEA_EINVAL, "embed: d_model=%d must be a multiple of 4 and <= 4096", C);
+    hipLaunchKernelGGL(embed_stats_kernel, dim3(B * T), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb, x, stats,
+                       T, C, vocab, pos_rows, absolute_pos);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// greedy finalize: argmax over the per-tile partials of each row, then the sampler-loop
+// bookkeeping of api_cache.py:179-181 (append, EOS stop) -- one 64-thread workgroup per row.
+__global__ __launch_bounds__(64) void argmax_advance_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                           int n_tiles, StepState s, int32_t* __restrict__ sampled) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n_tiles; i += 64) {
+        const float v = pval[(int64_t)b * n_tiles + i];
+        const int ix = pidx[(int64_t)b * n_tiles + i];
+        if (v > best || (v == best && ix < bi)) { best = v; bi = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const int tok = bi == 0x7fffffff ? 0 : bi;
+        sampled[b] = tok;
+        const int step = s.row_step[b];
+        int out = -1;
+        if (!s.done[b]) {
+            out = tok;
+            s.cur_ids[b] = tok;
+            s.ctx_len[b] += 1;
+            if (tok == s.eos_id) {
+                s.done[b] = 1;
+                atomicAdd(s.n_done, 1);
+            }
+        }
+        if (s.ids_out && step < s.n_steps) s.ids_out[(int64_t)b * s.n_steps + step] = out;
+        s.row_step[b] = step + 1;
+    }
+}
+
+int launch_argmax_advance(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
+                          int B, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_advance_kernel, dim3(B), dim3(64), 0, st, pval, pidx, n_tiles, s, sampled);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+}  // namespace mgea
