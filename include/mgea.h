@@ -183,6 +183,14 @@ int mgea_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev
 int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const int32_t* mask_dev,
                           float* out_dev, int32_t B, int32_t T, int32_t n_head, int32_t head_dim,
                           void* stream);
+/* Fused skinny GEMM (decode step, M <= 64): out = epilogue(LN?(A) @ W^T + bias); epi 1 = residual
+ * add into out + LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU).  LN prologue
+ * when lnw_dev != NULL (stats_in_dev [M][n_part][2] partial (mean, M2) over part_cnt columns).
+ * dbg = 0 (ablation bits for tools/skinny_bench.py). */
+int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev,
+                   const float* lnw_dev, const float* lnb_dev, const float* stats_in_dev, int32_t n_part,
+                   int32_t part_cnt, float* out_dev, float* stats_out_dev, int32_t M, int32_t N, int32_t K,
+                   int32_t act, int32_t dbg, void* stream);
 /* Sampler on a logits matrix [B,V]; step selects the Philox counter.  probs_out_dev [B,V] or NULL
  * receives the pre-multinomial distribution. */
 int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s,

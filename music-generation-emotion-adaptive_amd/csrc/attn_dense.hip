@@ -20,7 +20,7 @@ namespace mgea {
 template <int DH>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lens,
                                                         const int32_t* __restrict__ mask, float* __restrict__ out,
-                                                        int T, int H, float scale) {
+                                                        int T, int H, float scale, int tiled_out) {
     constexpr int NCH = DH / 4;   // 16-B chunks per row
     constexpr int DC = DH / 16;   // 16-wide d tiles
     constexpr int F4 = 64 * NCH / 256;
@@ -140,22 +140,23 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict
     lsum += __shfl_xor(lsum, 32, 64);
     if (q_in) {
         const float inv = 1.0f / lsum;
-        float* orow = out + (row0 + qrow) * C + h * DH;
 #pragma unroll
-        for (int dt = 0; dt < DC; ++dt)
-            st4(orow + dt * 16 + 4 * g,
-                make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv));
+        for (int dt = 0; dt < DC; ++dt) {
+            const int n = h * DH + dt * 16 + 4 * g;
+            float* dst = tiled_out ? out + tiled_off((int)(row0 + qrow), n) : out + (row0 + qrow) * C + n;
+            st4(dst, make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv));
+        }
     }
 }
 
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T, int H,
-                      int dh, hipStream_t st) {
+                      int dh, int tiled_out, hipStream_t st) {
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "attention: bad shape B=%d T=%d H=%d", B, T, H);
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(ceil_div(T, 64), H, B);
     switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale); break;
-        case 64: hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale); break;
+        case 32: hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
+        case 64: hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
         default:
             MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64)", dh);
     }

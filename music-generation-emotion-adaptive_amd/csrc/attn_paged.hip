@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
                                                         const int32_t* __restrict__ page_table, int max_pages,
                                                         const int32_t* __restrict__ ctx_len,
                                                         const int32_t* __restrict__ lens, float* __restrict__ out,
-                                                        int H, int T, int C, float scale) {
+                                                        int H, int T, int C, float scale, int tiled_out) {
     constexpr int NCH = DH / 4;        // 16-byte chunks per head row
     constexpr int TPI = 64 / NCH;      // tokens per V wave-instruction
     constexpr int NVI = 64 / TPI;      // V wave-instructions per page (= NCH)
@@ -39,9 +39,9 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_new = lens ? lens[b] : T;
     const int64_t m = (int64_t)b * T + t;
-    float* orow = out + m * C + h * DH;
+    auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d) : out + m * C + h * DH + d; };
     if (t >= n_new) {  // padded query row: defined output, never used
-        if (threadIdx.x < DH) orow[threadIdx.x] = 0.f;
+        if (threadIdx.x < DH) *optr(threadIdx.x) = 0.f;
         return;
     }
     const int len = ctx_len[b] + n_new;  // tokens visible to this query (whole cache, no mask)
@@ -59,16 +59,24 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     float mx = -INFINITY, lsum = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int pg = wave; pg < npages; pg += 4) {
+    // Software pipeline over this wave's pages: while QK^T consumes K(page) the V(page) loads are in
+    // flight, and while PV consumes V(page) the K(next page) loads are -- each wave keeps 16 KiB
+    // (one operand tile) streaming at all times.  K/V are read once per step: non-temporal loads.
+    float4 kk[NCH], vv[NVI];
+    auto page_base = [&](int pg, int isv) {
         const int phys = page_table[b * max_pages + pg];
-        const float* kpage = lbase + ((int64_t)(phys * 2 + 0) * H + h) * pf;
-        const float* vpage = lbase + ((int64_t)(phys * 2 + 1) * H + h) * pf;
-        // issue all K and V loads of the page up front (32 KiB in flight per wave at dh = 64)
-        float4 kk[NCH], vv[NVI];
+        return lbase + ((int64_t)(phys * 2 + isv) * H + h) * pf;
+    };
+    auto load_k = [&](int pg) {
+        const float* kpage = page_base(pg, 0);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) kk[i] = ld4(kpage + (i * 64 + lane) * 4);
+        for (int i = 0; i < NCH; ++i) kk[i] = ldnt4(kpage + (i * 64 + lane) * 4);
+    };
+    if (wave < npages) load_k(wave);
+    for (int pg = wave; pg < npages; pg += 4) {
+        const float* vpage = page_base(pg, 1);
 #pragma unroll
-        for (int j = 0; j < NVI; ++j) vv[j] = ld4(vpage + (j * TPI + g) * DH + c * 4);
+        for (int j = 0; j < NVI; ++j) vv[j] = ldnt4(vpage + (j * TPI + g) * DH + c * 4);
 
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         lsum = lsum * alpha + p;
         acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
         mx = mnew;
+        if (pg + 4 < npages) load_k(pg + 4);  // K registers are free again: next page's K under PV
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {
             const float pj = __shfl(p, j * TPI + g, 64);
@@ -126,21 +135,22 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
             num = fmaf(f, s_acc[w][threadIdx.x], num);
             den = fmaf(f, s_l[w], den);
         }
-        orow[threadIdx.x] = num / den;
+        *optr(threadIdx.x) = num / den;
     }
 }
 
 int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages,
-                      const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T, int C, hipStream_t st) {
+                      const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T, int C, int tiled_out,
+                      hipStream_t st) {
     const int H = pool.H, dh = pool.dh;
     MGEA_REQUIRE(H * dh == C, MGEA_EINVAL, "attention: n_head*head_dim != d_model");
     MGEA_REQUIRE(T <= 65535, MGEA_EINVAL, "attention: too many new tokens per row (%d)", T);
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(B * H, T);
     switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_paged_kernel<32>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale); break;
-        case 64: hipLaunchKernelGGL(attn_paged_kernel<64>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale); break;
-        case 128: hipLaunchKernelGGL(attn_paged_kernel<128>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale); break;
+        case 32: hipLaunchKernelGGL(attn_paged_kernel<32>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
+        case 64: hipLaunchKernelGGL(attn_paged_kernel<64>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
+        case 128: hipLaunchKernelGGL(attn_paged_kernel<128>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
         default:
             MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 128)", dh);
     }

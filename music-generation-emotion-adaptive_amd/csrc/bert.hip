@@ -149,7 +149,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         MGEA_TRY(gemm(h->h, D, h->lw(l, BL_QKVW), M, 3 * D, D, &Sk));
         MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
                                  3 * D, M, 3 * D, ACT_NONE, st));
-        MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, st));
+        MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, 0, st));
         MGEA_TRY(gemm(h->ctx, D, h->lw(l, BL_OUTW), M, D, D, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->h, nullptr,
                                     h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, M, D, 1, st));

@@ -61,7 +61,20 @@ int mgea_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev
 int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const int32_t* mask_dev, float* out_dev,
                           int32_t B, int32_t T, int32_t n_head, int32_t head_dim, void* stream) {
     MGEA_REQUIRE(qkv_dev && out_dev, MGEA_EINVAL, "op_attention: NULL argument");
-    return launch_attn_dense(qkv_dev, lens_dev, mask_dev, out_dev, B, T, n_head, head_dim, (hipStream_t)stream);
+    return launch_attn_dense(qkv_dev, lens_dev, mask_dev, out_dev, B, T, n_head, head_dim, 0, (hipStream_t)stream);
+}
+
+/* ablation / micro-benchmark hook for the fused skinny GEMM (tools/skinny_bench.py): EPI_ACT or
+ * EPI_RES on caller buffers; dbg bits skip A loads (1), W loads (2), MFMAs (4). */
+int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev, const float* lnw_dev,
+                   const float* lnb_dev, const float* stats_in_dev, int32_t n_part, int32_t part_cnt, float* out_dev,
+                   float* stats_out_dev, int32_t M, int32_t N, int32_t K, int32_t act, int32_t dbg, void* stream) {
+    SkinnyArgs a{};
+    a.A = a_dev; a.lda = K; a.W = w_dev; a.bias = bias_dev; a.M = M; a.N = N; a.K = K;
+    a.lnw = lnw_dev; a.lnb = lnb_dev; a.eps = 1e-5f; a.stats_in = stats_in_dev; a.n_part = n_part; a.part_cnt = part_cnt;
+    a.out = out_dev; a.ldo = N; a.stats_out = stats_out_dev; a.act = act; a.dbg = dbg;
+    MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
+    return launch_skinny(epi, a, (hipStream_t)stream);
 }
 
 int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s, int64_t step,

@@ -40,6 +40,12 @@ const char* get_error();
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// "k-tiled" activation layout of the fused decode path: [k/32][64 rows][32]; element (row, n) of a
+// [<=64, N] matrix.  One 32-wide k-chunk of all 64 rows is 8 KB contiguous, so the A fragments of the
+// skinny GEMM (16 rows x 128 B per wave instruction pair) are whole, adjacent cache lines instead
+// of 16 lines that are a full row pitch (2-8 KB) apart.
+__host__ __device__ static inline int64_t tiled_off(int row, int n) { return ((int64_t)(n >> 5) * 64 + row) * 32 + (n & 31); }
+
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
 
 // P[z][M, ldp] = A[M, k-slice z] @ W[N, k-slice z]^T   (raw partial products, no bias)
@@ -91,10 +97,10 @@ int launch_qkv_scatter(const float* P, int S, int64_t ps, int ldp, const float* 
 // ctx_len[b] + (lens ? lens[b] : T) cached tokens.  q read from qkv[m, 0:C] (row stride 3C).
 int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int32_t* page_table,
                       int max_pages, const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T,
-                      int C, hipStream_t st);
+                      int C, int tiled_out, hipStream_t st);
 // dense non-causal attention over the qkv buffer itself (prefill without past, BERT)
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T,
-                      int H, int dh, hipStream_t st);
+                      int H, int dh, int tiled_out, hipStream_t st);
 
 // logits row epilogue: v = sum P + bias; optional store to logits[m, V]; greedy argmax path writes
 // next ids and advances the per-row state (see decoder.hip).
@@ -145,6 +151,7 @@ struct SkinnyArgs {
     const int32_t* lens; int T; int C;
     // LOGITS
     float* pmax_val; int32_t* pmax_idx;   // [64][n_tiles]
+    int dbg;                   // ablation bits for tools/skinny_bench.py (0 in production)
 };
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
@@ -174,6 +181,11 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// non-temporal 16-byte load for data streamed once (KV pages): does not displace L2/MALL lines
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 }  // namespace mgea
 #endif

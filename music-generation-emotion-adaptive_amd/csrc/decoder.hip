@@ -229,9 +229,9 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
         }
         if (use_cache_attn) {
             PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T,
-                                       C, st));
+                                       C, 0, st));
         } else {
-            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, st));
+            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, 0, st));
         }
         MGEA_TRY(gemm(h, h->att, C, h->lw(l, L_OUTW), M, C, C, &S, st));
         if (post) {
@@ -279,9 +279,9 @@ int run_blocks_fused(mgea_decoder* h, int B, int T, const int32_t* lens, bool us
         a.lens = lens; a.T = T; a.C = C;
         PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
         if (use_cache_attn) {
-            PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T, C, st));
+            PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T, C, 1, st));
         } else {
-            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, st));
+            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, 1, st));
         }
         // out_proj + residual (+ stats for ln2)
         SkinnyArgs o{};
@@ -418,7 +418,12 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
                                  V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, st));
         MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
     }
-    if (logits_out) {
+    if (logits_out && fused_ok(h, (int)M)) {
+        SkinnyArgs a{};  // x is k-tiled on the fused path: the head is the skinny LOGITS kernel
+        a.M = (int)M; a.A = h->x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
+        a.out = logits_out; a.ldo = V;
+        MGEA_TRY(launch_skinny(EPI_LOGITS, a, st));
+    } else if (logits_out) {
         for (int64_t r0 = 0; r0 < M; r0 += 4096) {
             const int rows = (int)((M - r0) < 4096 ? (M - r0) : 4096);
             int S = 1;

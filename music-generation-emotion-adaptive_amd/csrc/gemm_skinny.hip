@@ -5,111 +5,83 @@
 // Reference ops covered (api_cache.py): ln1 + in_proj + cache append (:60-67), out_proj + residual
 // (:68,72), ln2 + mlp.0 + GELU (:73), mlp.2 + residual (:73), head (:105) + greedy argmax.
 //
-// Decomposition (gfx950): one workgroup = ALL 64 rows x 16 output columns; its NW waves split K
-// (wave w owns k in [w*K/NW, (w+1)*K/NW)), each streaming its W slice straight from HBM into
-// registers (weights are read exactly once per step, 32 contiguous bytes per lane, full 128-B
-// lines per row) and its A slice from L2; products are v_mfma_f32_16x16x4_f32 (exact fp32) issued
-// "swapped" so a lane owns 4 consecutive output columns.  The NW partial tiles are summed through
-// LDS in wave order (deterministic), then 256 threads run the epilogue on float4s.
+// Decomposition (gfx950): one workgroup = (16*MT rows) x (16 output columns) over the FULL K; its
+// NW waves split K (wave w owns k in [w*K/NW, (w+1)*K/NW)) and their partial tiles are summed
+// through LDS in wave order (deterministic, no atomics, no slabs).  MT in {1,2,4} is chosen per
+// GEMM so that every launch has >= ~128-512 workgroups (the N of these GEMMs is only 512..2048):
+// the MFMA work of a 64-row problem has to be spread over all 1024 SIMDs, and the bytes a CU pulls
+// through its L2 port (~45-70 GB/s per CU) stay at 64-256 KB.  Workgroups that share a W tile differ
+// by a multiple of gridDim.x (a multiple of 8) in dispatch order -> same XCD, so W is fetched from
+// HBM once and re-read from that XCD's L2 (speed only; results never depend on placement).
+//   * operands go HBM/L2 -> registers directly (32 contiguous bytes per lane); activations use the
+//     k-tiled layout of common.h (tiled_off) so an A fragment load is 16 adjacent 128-B lines;
+//   * v_mfma_f32_16x16x4_f32 (exact fp32), issued "swapped" so a lane owns 4 consecutive output
+//     columns; the k order inside the chain is a fixed permutation (k = k0 + 8g + 4h + s) applied
+//     to both operands; results are run-to-run bit-identical;
 //   * LN prologue: the PRODUCER of x (embedding or a residual epilogue) leaves per-row partial
 //     statistics (mean, M2) per 16-column tile; the consumer merges them with Chan's formula
-//     (16 KB instead of re-reading 128 KB of x) and normalises A fragments in registers.
-//   * k order inside the MFMA chain is a fixed permutation (k = k0 + 8g + 4h + s) applied to both
-//     operands; results are run-to-run bit-identical.
+//     and normalises its A fragments in registers.
 #include "common.h"
 
 namespace mgea {
 
-template <int EPI, bool LN>
-__global__ __launch_bounds__(LN ? 256 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][64][16] (+ 128 floats of LN stats)
-    float* s_mean = red + (blockDim.x >> 6) * 64 * 16;             // all LDS in ONE array (16-B aligned carve)
-    float* s_rstd = s_mean + 64;
+template <int EPI, bool LN, int MT>
+__global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
+    constexpr int ROWS = 16 * MT;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][16] (+ 2*ROWS floats of LN stats)
+    float* s_mean = red + (blockDim.x >> 6) * ROWS * 16;           // all LDS in ONE array (16-B aligned carve)
+    float* s_rstd = s_mean + ROWS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * ROWS;
     const int kw = a.K / NW, kbeg = wave * kw;
     const int nchunk = kw >> 5;
 
-    if (LN) {
-        // merge the producer's per-tile (mean, M2) partials: thread t -> row t>>2, partials q, q+4, ...
-        if (tid < 256) {
-            const int row = tid >> 2, q = tid & 3;
-            float n = 0.f, mean = 0.f, m2 = 0.f;
-            if (row < a.M) {
-                const float* sp = a.stats_in + ((int64_t)row * a.n_part) * 2;
-                const float cnt = (float)a.part_cnt;
-                for (int p = q; p < a.n_part; p += 4) {
-                    const float2 s = *reinterpret_cast<const float2*>(sp + 2 * p);
-                    const float nn = n + cnt, d = s.x - mean;
-                    mean += d * (cnt / nn);
-                    m2 += s.y + d * d * (n * cnt / nn);
-                    n = nn;
-                }
-            }
+    // k-tiled A: rows >= M of the 64-row buffer hold stale data whose products are never stored
+    const float* arow[MT];
 #pragma unroll
-            for (int o = 1; o <= 2; o <<= 1) {
-                const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64), m22 = __shfl_xor(m2, o, 64);
-                const float nn = n + n2;
-                if (nn > 0.f) {
-                    const float d = mean2 - mean;
-                    mean += d * (n2 / nn);
-                    m2 += m22 + d * d * (n * n2 / nn);
-                }
-                n = nn;
-            }
-            if (q == 0) {
-                s_mean[row] = mean;
-                s_rstd[row] = (n > 0.f) ? 1.0f / sqrtf(m2 / n + a.eps) : 0.f;
-            }
-        }
-        __syncthreads();
-    }
-
-    // rows of this lane's A fragments (clamped: rows >= M compute garbage that is never stored)
-    const float* arow[4];
-    float mu[4], rs[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int r = mt * 16 + c;
-        if (LN) { mu[mt] = s_mean[r]; rs[mt] = s_rstd[r]; }
-        r = r < a.M ? r : a.M - 1;
-        arow[mt] = a.A + (int64_t)r * a.lda + kbeg + 8 * g;
-    }
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = a.A + tiled_off(m0 + mt * 16 + c, kbeg + 8 * g);
     int wr = n0 + c;
     wr = wr < a.N ? wr : a.N - 1;
     const float* wrow = a.W + (int64_t)wr * a.K + kbeg + 8 * g;
     const float* gptr = a.lnw + kbeg + 8 * g;
     const float* bptr = a.lnb + kbeg + 8 * g;
 
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wf[2][2], af[2][4][2], gf[2][2], bf[2][2];
+    float4 wf[2][2] = {}, af[2][MT][2] = {}, gf[2][2], bf[2][2];
     auto load_chunk = [&](int buf, int ch) {
         const int ko = ch * 32;
-        wf[buf][0] = ld4(wrow + ko);
-        wf[buf][1] = ld4(wrow + ko + 4);
+        if (!(a.dbg & 2)) {
+            wf[buf][0] = ld4(wrow + ko);
+            wf[buf][1] = ld4(wrow + ko + 4);
+        }
+        if (!(a.dbg & 1)) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            af[buf][mt][0] = ld4(arow[mt] + ko);
-            af[buf][mt][1] = ld4(arow[mt] + ko + 4);
+            for (int mt = 0; mt < MT; ++mt) {
+                af[buf][mt][0] = ld4(arow[mt] + (int64_t)ch * 64 * 32);
+                af[buf][mt][1] = ld4(arow[mt] + (int64_t)ch * 64 * 32 + 4);
+            }
         }
         if (LN) {
             gf[buf][0] = ld4(gptr + ko); gf[buf][1] = ld4(gptr + ko + 4);
             bf[buf][0] = ld4(bptr + ko); bf[buf][1] = ld4(bptr + ko + 4);
         }
     };
+    float mu[MT], rs[MT];
     auto compute_chunk = [&](int buf) {
+        if (a.dbg & 4) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float4 w4 = wf[buf][h];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 float4 x = af[buf][mt][h];
                 if (LN) {
                     const float4 gg = gf[buf][h], bb = bf[buf][h];
@@ -125,29 +97,63 @@ __global__ __launch_bounds__(LN ? 256 : 1024) void gemm_skinny_kernel(SkinnyArgs
             }
         }
     };
+    // every wave puts its first two k-chunks in flight before anything else (the kernel is
+    // latency-bound), then the LN statistics are merged under that flight
     load_chunk(0, 0);
+    if (nchunk > 1) load_chunk(1, 1);
+    if (LN) {
+        // merge the producer's per-tile (mean, M2) partials: thread t -> row t>>2, partials q, q+4, ...
+        if (tid < ROWS * 4) {
+            const int lr = tid >> 2, q = tid & 3, row = m0 + lr;
+            // every partial covers the same number of columns (part_cnt), so
+            //   mean = average of the tile means,  M2 = sum M2_t + part_cnt * sum (mean_t - mean)^2
+            const bool ok = row < a.M;
+            const float* sp = a.stats_in + ((int64_t)(ok ? row : 0) * a.n_part) * 2;
+            float sm = 0.f;
+            for (int p = q; p < a.n_part; p += 4) sm += sp[2 * p];
+            sm += __shfl_xor(sm, 1, 64);
+            sm += __shfl_xor(sm, 2, 64);
+            const float mean = sm * (1.0f / (float)a.n_part);
+            const float cnt = (float)a.part_cnt;
+            float m2 = 0.f;
+            for (int p = q; p < a.n_part; p += 4) {
+                const float2 s = *reinterpret_cast<const float2*>(sp + 2 * p);
+                const float d = s.x - mean;
+                m2 += s.y + cnt * d * d;
+            }
+            m2 += __shfl_xor(m2, 1, 64);
+            m2 += __shfl_xor(m2, 2, 64);
+            if (q == 0) {
+                s_mean[lr] = ok ? mean : 0.f;
+                s_rstd[lr] = ok ? 1.0f / sqrtf(m2 / (cnt * (float)a.n_part) + a.eps) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + c]; rs[mt] = s_rstd[mt * 16 + c]; }
+    }
     for (int ch = 0; ch < nchunk; ch += 2) {
-        if (ch + 1 < nchunk) load_chunk(1, ch + 1);
         compute_chunk(0);
+        if (ch + 2 < nchunk) load_chunk(0, ch + 2);
         if (ch + 1 < nchunk) {
-            if (ch + 2 < nchunk) load_chunk(0, ch + 2);
             compute_chunk(1);
+            if (ch + 3 < nchunk) load_chunk(1, ch + 3);
         }
     }
 
     // partial tile of this wave -> LDS: D[i = column 4g + r][j = row c]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-        *reinterpret_cast<float4*>(&red[((wave * 64) + mt * 16 + c) * 16 + 4 * g]) =
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * 16 + 4 * g]) =
             make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
     __syncthreads();
 
-    // epilogue: thread t -> row t >> 2, columns n0 + 4*(t & 3) .. +3
-    for (int t = tid; t < 256; t += blockDim.x) {
-        const int row = t >> 2, q = t & 3;
+    // epilogue: thread t -> local row t >> 2, columns n0 + 4*(t & 3) .. +3
+    for (int t = tid; t < ROWS * 4; t += blockDim.x) {
+        const int lr = t >> 2, q = t & 3, row = m0 + lr;
         const int n = n0 + 4 * q;
-        float4 v = *reinterpret_cast<const float4*>(&red[row * 16 + 4 * q]);
-        for (int w = 1; w < NW; ++w) v = add4(v, *reinterpret_cast<const float4*>(&red[(w * 64 + row) * 16 + 4 * q]));
+        float4 v = *reinterpret_cast<const float4*>(&red[lr * 16 + 4 * q]);
+        for (int w = 1; w < NW; ++w) v = add4(v, *reinterpret_cast<const float4*>(&red[(w * ROWS + lr) * 16 + 4 * q]));
         const bool row_ok = row < a.M;
         if (EPI != EPI_LOGITS) {
             // N % 16 == 0 for these epilogues (checked on the host)
@@ -156,10 +162,10 @@ __global__ __launch_bounds__(LN ? 256 : 1024) void gemm_skinny_kernel(SkinnyArgs
         if (EPI == EPI_ACT) {
             if (a.act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
             if (a.act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-            if (row_ok) st4(a.out + (int64_t)row * a.ldo + n, v);
+            if (row_ok) st4(a.out + tiled_off(row, n), v);   // hbuf is k-tiled for the FC2 kernel
         }
         if (EPI == EPI_RES) {
-            float* xp = a.out + (int64_t)row * a.ldo + n;
+            float* xp = a.out + tiled_off(row, n);           // residual stream x is k-tiled
             if (row_ok) {
                 v = add4(v, ld4(xp));
                 st4(xp, v);
@@ -223,28 +229,55 @@ __global__ __launch_bounds__(LN ? 256 : 1024) void gemm_skinny_kernel(SkinnyArgs
     }
 }
 
-static int pick_waves(int K, bool ln) {
-    if (ln) return 4;  // the LN merge uses exactly 256 threads
-    for (int nw = 16; nw >= 1; --nw)
-        if (K % (32 * nw) == 0 && K / nw >= 128) return nw;
-    for (int nw = 16; nw >= 1; --nw)
-        if (K % (32 * nw) == 0) return nw;
+// rows per workgroup: enough workgroups to cover the chip, as few re-reads of W as possible
+static int pick_mt(int M, int N) {
+    // measured on MI355X (tools/skinny_bench.py, profiles/r1_skinny_sweep.txt): 32 rows per workgroup
+    // once N/16 >= 64 tiles (QKV, FC1, head), 16 rows for the N = 512 projections; 64 rows never wins
+    const int tiles_n = ceil_div(N, 16);
+    int mt = tiles_n >= 64 ? 2 : 1;
+    while (mt > 1 && 16 * (mt / 2) >= M) mt /= 2;  // never more rows than the problem has
+    return mt;
+}
+
+static int pick_waves(int K, bool ln, int mt) {
+    // as many waves as there are 32-wide k-chunks, <= 16 (<= 8 for the register-heavy LN x 64-row
+    // variant): few chunks per wave = few dependent memory round trips.  The LN merge needs
+    // 4 threads per row of the tile.
+    const int cap = 8;  // 16 waves per workgroup measured equal or slower on every decode shape
+    for (int nw = cap; nw >= 1; --nw)
+        if ((K / 32) % nw == 0) return nw;
     return 1;
+}
+
+template <int EPI, int MT>
+static int launch_skinny_mt(const SkinnyArgs& a, int nw, hipStream_t st) {
+    const bool ln = a.lnw != nullptr;
+    dim3 grid(ceil_div(a.N, 16), ceil_div(a.M, 16 * MT)), block(64 * nw);
+    const size_t shmem = ((size_t)nw * 16 * MT * 16 + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
+    if (ln) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT>), grid, block, shmem, st, a);
+    else    hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT>), grid, block, shmem, st, a);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
 }
 
 template <int EPI>
 static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     const bool ln = a.lnw != nullptr;
-    const int nw = pick_waves(a.K, ln);
     MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
-    MGEA_REQUIRE(a.K % (32 * nw) == 0 && (a.lda % 4) == 0, MGEA_EINVAL, "skinny gemm: K=%d not divisible by %d", a.K, 32 * nw);
+    MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
-    dim3 grid(ceil_div(a.N, 16)), block(64 * nw);
-    const size_t shmem = ((size_t)nw * 64 * 16 + (ln ? 128 : 0)) * sizeof(float);
-    if (ln) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), grid, block, shmem, st, a);
-    else    hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false>), grid, block, shmem, st, a);
-    MGEA_CHECK_HIP(hipGetLastError());
-    return MGEA_OK;
+    const int mt = ((a.dbg >> 8) & 15) ? ((a.dbg >> 8) & 15) : pick_mt(a.M, a.N);
+    int nw = pick_waves(a.K, ln, mt);
+    if ((a.dbg >> 12) & 31) nw = (a.dbg >> 12) & 31;  // tools/skinny_bench.py override
+    MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= ((ln && mt == 4) ? 8 : 16), MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
+    MGEA_REQUIRE(!ln || nw * 64 >= 16 * mt * 4, MGEA_EINVAL, "skinny gemm: LN prologue needs K %% 128 == 0 (K=%d)", a.K);
+    switch (mt) {
+        case 1: return launch_skinny_mt<EPI, 1>(a, nw, st);
+        case 2: return launch_skinny_mt<EPI, 2>(a, nw, st);
+        case 4: return launch_skinny_mt<EPI, 4>(a, nw, st);
+    }
+    set_error("skinny gemm: bad row-tile count %d", mt);
+    return MGEA_EINVAL;
 }
 
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
@@ -259,7 +292,7 @@ int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// x[m] = tok_emb[ids[m]] + pos_emb[pos]; stats[m] = (mean, M2) of the row (one partial)
+// x[m] = tok_emb[ids[m]] + pos_emb[pos] (k-tiled); stats[m] = (mean, M2) of the row (one partial)
 __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
                                                          const int32_t* __restrict__ ctx_len,
                                                          const float* __restrict__ tok_emb,
@@ -283,7 +316,7 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restr
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f < nf4) {
             if (real) v[i] = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
-            st4(x + m * C + f * 4, v[i]);
+            st4(x + tiled_off((int)m, f * 4), v[i]);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -312,6 +345,7 @@ int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* c
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
                        int absolute_pos, hipStream_t st) {
     MGEA_REQUIRE(C % 4 == 0 && C <= 4096, MGEA_EINVAL, "embed: d_model=%d must be a multiple of 4 and <= 4096", C);
+    MGEA_REQUIRE(B * T <= 64, MGEA_EINVAL, "embed (fused path): more than 64 rows");
     hipLaunchKernelGGL(embed_stats_kernel, dim3(B * T), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb, x, stats,
                        T, C, vocab, pos_rows, absolute_pos);
     MGEA_CHECK_HIP(hipGetLastError());
