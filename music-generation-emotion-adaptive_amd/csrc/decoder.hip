@@ -79,6 +79,7 @@ struct mgea_decoder {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *slabs = nullptr,
           *logits = nullptr, *stats = nullptr, *pmax_val = nullptr;
     int32_t* pmax_idx = nullptr;
+    bool no_graph = false;       // MGEA_DECODER_NOGRAPH=1: launch every step eagerly (rocprofv3 --pmc runs)
     bool force_unfused = false;  // MGEA_DECODER_UNFUSED=1: keep the 9-launch-per-layer path (A/B and fallback)
     int64_t slab_cap = 0;
     // graph of one decode step
@@ -474,6 +475,8 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     {
         const char* e = getenv("MGEA_DECODER_UNFUSED");
         h->force_unfused = e && e[0] == '1';
+        const char* g = getenv("MGEA_DECODER_NOGRAPH");
+        h->no_graph = g && g[0] == '1';
     }
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
@@ -574,7 +577,7 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
     if (n_steps == 0) return MGEA_OK;
 
     // capture one decode step (all per-step state lives in device memory, so one graph serves every step)
-    if (!h->gexec || h->g_batch != B || !same_sampler(h->g_samp, *s)) {
+    if (!h->no_graph && (!h->gexec || h->g_batch != B || !same_sampler(h->g_samp, *s))) {
         drop_graph(h);
         MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = enqueue_step(h, B, *s, nullptr, st);
@@ -601,6 +604,8 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
             const int rc = enqueue_step(h, B, *s, nullptr, st);
             h->prof_now = false;
             MGEA_TRY(rc);
+        } else if (h->no_graph) {
+            MGEA_TRY(enqueue_step(h, B, *s, nullptr, st));
         } else {
             MGEA_CHECK_HIP(hipGraphLaunch(h->gexec, st));
         }

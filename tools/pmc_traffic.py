@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Aggregate a rocprofv3 --pmc counter_collection.csv: per-kernel mean of a counter per dispatch.
+usage: pmc_traffic.py <counter_collection.csv> <COUNTER> [name-substring]"""
+import csv, sys, collections, json
+path, counter = sys.argv[1], sys.argv[2]
+pat = sys.argv[3] if len(sys.argv) > 3 else ""
+tot, cnt = collections.Counter(), collections.Counter()
+with open(path) as f:
+    for r in csv.DictReader(f):
+        if r.get("Counter_Name") != counter:
+            continue
+        name = r["Kernel_Name"]
+        if pat and pat not in name:
+            continue
+        tot[name] += float(r["Counter_Value"]); cnt[name] += 1
+out = {k[:80]: dict(dispatches=cnt[k], mean=tot[k] / cnt[k], total=tot[k]) for k in tot}
+print(json.dumps(out, indent=1))
