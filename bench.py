@@ -85,13 +85,14 @@ def cpu_baseline_decoder(sd, prompts, budget_s):
                        f"steps (ctx <= {idx.shape[1] + n}), {dt:.1f} s")
 
 
-def bert_extra(device, steps, warmup, with_cpu):
+def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None):
     from mgea import synth
     from mgea.bert import BertEngine
     B, S = 256, 128
-    sd = synth.distilbert_state_dict(41, BERT["vocab"], BERT["max_pos"], BERT["dim"], BERT["n_layers"], BERT["hidden"])
-    ad = synth.lora_adapter(41, BERT["dim"], BERT["n_layers"])
-    eng = BertEngine(sd, n_heads=12, adapter=ad, max_tokens=B * S, device=device)
+    if sd is None:
+        sd = synth.distilbert_state_dict(41, BERT["vocab"], BERT["max_pos"], BERT["dim"], BERT["n_layers"], BERT["hidden"])
+        ad = synth.lora_adapter(41, BERT["dim"], BERT["n_layers"])
+    eng = BertEngine(sd, n_heads=12, adapter=ad, max_tokens=B * S, device=device, dtype=dtype)
     ids, mask = synth.bert_inputs(2, B, S, BERT["vocab"])
     ids, mask = torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)
     for _ in range(max(1, warmup)):
@@ -105,10 +106,10 @@ def bert_extra(device, steps, warmup, with_cpu):
     D, FF, L = BERT["dim"], BERT["hidden"], BERT["n_layers"]
     flops = 2 * B * S * L * (4 * D * D + 2 * D * FF) + 4 * B * S * S * D * L + 2 * B * (D * D + 28 * D)
     out = dict(metric="distilbert_prompts_per_sec", value=B / dt, unit="prompts/s", ms_per_batch=dt * 1e3,
-               dtype="f32", workload="DistilBERT-base(+LoRA merged) classifier B=256 S=128 padded rows, random weights",
-               roofline=dict(bound="mfma", achieved=flops / dt / 1e12, peak=157.3, unit="TFLOP/s",
-                             frac=flops / dt / 1e12 / 157.3, traffic=None,
-                             note="whole-forward algorithmic FLOPs / wall time vs the fp32 MFMA peak"))
+               dtype=dtype, workload="DistilBERT-base(+LoRA merged) classifier B=256 S=128 padded rows, random weights",
+               roofline=dict(bound="mfma", achieved=flops / dt / 1e12, peak=2500.0 if dtype == "bf16" else 157.3,
+                             unit="TFLOP/s", frac=flops / dt / 1e12 / (2500.0 if dtype == "bf16" else 157.3), traffic=None,
+                             note="whole-forward algorithmic FLOPs / wall time vs the dense MFMA peak of the dtype"))
     if with_cpu:
         from oracle.distilbert_ref import DistilBertRef
         ref = DistilBertRef(sd, 12, ad)
@@ -225,7 +226,8 @@ def main():
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_decoder(sd, prompts.tolist(), args.cpu_seconds)
         if not args.no_bert:
-            line["extra"] = {"distilbert": bert_extra(device, max(2, args.steps), 1, not args.no_cpu)}
+            line["extra"] = {"distilbert": bert_extra(device, max(2, args.steps), 1, not args.no_cpu),
+                             "distilbert_bf16": bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")}
     eng.close()
     barrier()
     if rank == 0:

@@ -183,6 +183,16 @@ int mgea_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev
 int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const int32_t* mask_dev,
                           float* out_dev, int32_t B, int32_t T, int32_t n_head, int32_t head_dim,
                           void* stream);
+/* bf16 perf-mode kernels (MGEA_DTYPE_BF16 engines); bf16 buffers are raw 16-bit storage.
+ * gemm: out[M,N] = epi(a[M,K] @ w[N,K]^T + bias), fp32 accumulate; epi 0 bias, 1 bias+GELU,
+ * 2 bias+residual(res_dev [M,N] bf16).  K % 64 == 0, N % 4 == 0.  attention: head_dim 64 only. */
+int mgea_op_f32_to_bf16(const float* src_dev, void* dst_dev, int64_t n, void* stream);
+int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
+                      void* out_dev, int32_t M, int32_t N, int32_t K, int32_t epi, void* stream);
+int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,
+                           int32_t n_head, int32_t head_dim, void* stream);
+int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int32_t M,
+                           int32_t C, float eps, void* stream);
 /* Fused skinny GEMM (decode step, M <= 64): out = epilogue(LN?(A) @ W^T + bias); epi 1 = residual
  * add into out + LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU).  LN prologue
  * when lnw_dev != NULL (stats_in_dev [M][n_part][2] partial (mean, M2) over part_cnt columns).

@@ -48,7 +48,10 @@ int validate(const mgea_bert_config* c) {
     const int dh = c->dim / c->n_heads;
     MGEA_REQUIRE(dh == 32 || dh == 64, MGEA_EINVAL, "head_dim %d not supported (32 or 64)", dh);
     MGEA_REQUIRE(c->dim % 32 == 0 && c->hidden % 32 == 0 && c->dim <= 4096, MGEA_EINVAL, "dim/hidden must be multiples of 32, dim <= 4096");
-    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32, MGEA_EINVAL, "bert dtype %d not built (f32 only in this build)", c->dtype);
+    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32 || c->dtype == MGEA_DTYPE_BF16, MGEA_EINVAL, "bert dtype %d unknown", c->dtype);
+    if (c->dtype == MGEA_DTYPE_BF16)
+        MGEA_REQUIRE(dh == 64 && c->dim % 64 == 0 && c->hidden % 64 == 0 && c->dim <= 2048, MGEA_EINVAL,
+                     "bf16 mode needs head_dim 64 and dim/hidden multiples of 64 (dim <= 2048)");
     return MGEA_OK;
 }
 }  // namespace
@@ -60,6 +63,8 @@ struct mgea_bert {
     std::mutex mu;
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *slabs = nullptr, *pooled = nullptr,
           *pooled2 = nullptr;
+    void *wb = nullptr, *hb = nullptr, *qkvb = nullptr, *ctxb = nullptr, *ffnb = nullptr, *tmpb = nullptr;  // bf16 mode
+    const char* wbf(int64_t off_floats) const { return (const char*)wb + off_floats * 2; }
     int64_t slab_cap = 0;
     const float* w(int i) const { return arena + off[i]; }
     const float* lw(int l, int j) const { return arena + off[B_HEAD0 + l * BL_COUNT + j]; }
@@ -84,7 +89,7 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_destroy(mgea_bert* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2};
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;
@@ -111,10 +116,24 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
     const int64_t head = 32 * (int64_t)(M < 64 ? M : 64) * slab_ld((int)D);
     slab = slab > head ? slab : head;
     h->slab_cap = slab;
-    bool ok = hipMalloc((void**)&h->h, M * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, M * 3 * D * 4) == hipSuccess &&
-              hipMalloc((void**)&h->ctx, M * D * 4) == hipSuccess && hipMalloc((void**)&h->ffn, M * Hd * 4) == hipSuccess &&
-              hipMalloc((void**)&h->slabs, slab * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
-              hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+    bool ok;
+    if (cfg->dtype == MGEA_DTYPE_BF16) {
+        // perf mode: bf16 copy of the whole arena (same offsets), bf16 activations; the classifier head
+        // (M = batch rows) stays on the fp32 kernels
+        const int64_t small = 32 * 64 * slab_ld((int)D), big = M * slab_ld((int)D);  // split-K (B <= 64) / one slab
+        h->slab_cap = small > big ? small : big;
+        ok = hipMalloc(&h->wb, total * 2) == hipSuccess && hipMalloc(&h->hb, M * D * 2) == hipSuccess &&
+             hipMalloc(&h->qkvb, M * 3 * D * 2) == hipSuccess && hipMalloc(&h->ctxb, M * D * 2) == hipSuccess &&
+             hipMalloc(&h->ffnb, M * Hd * 2) == hipSuccess && hipMalloc(&h->tmpb, M * D * 2) == hipSuccess &&
+             hipMalloc((void**)&h->slabs, h->slab_cap * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
+             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+        if (ok) ok = launch_f32_to_bf16(arena_dev, h->wb, total, nullptr) == MGEA_OK && hipDeviceSynchronize() == hipSuccess;
+    } else {
+        ok = hipMalloc((void**)&h->h, M * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, M * 3 * D * 4) == hipSuccess &&
+             hipMalloc((void**)&h->ctx, M * D * 4) == hipSuccess && hipMalloc((void**)&h->ffn, M * Hd * 4) == hipSuccess &&
+             hipMalloc((void**)&h->slabs, slab * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
+             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+    }
     if (!ok) {
         set_error("bert_create: out of device memory");
         mgea_bert_destroy(h);
@@ -142,9 +161,25 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         *Sout = rc;
         return MGEA_OK;
     };
+    int Sk = 1;
+    if (c.dtype == MGEA_DTYPE_BF16) {
+        // perf mode: bf16 MFMA GEMMs with fused bias / GELU / residual epilogues, bf16 flash attention
+        auto wb = [&](int l, int j) { return (const void*)h->wbf(h->off[B_HEAD0 + l * BL_COUNT + j]); };
+        MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
+                                           S, D, c.vocab, st));
+        for (int l = 0; l < c.n_layers; ++l) {
+            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st));
+            MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
+            MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2, st));
+            MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->hb, M, D, c.ln_eps, st));
+            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_L1W), D, h->lw(l, BL_L1B), nullptr, h->ffnb, Hd, M, Hd, D, 1, st));
+            MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2, st));
+            MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
+        }
+        MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+    } else {
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
                                   D, c.vocab, st));
-    int Sk = 1;
     for (int l = 0; l < c.n_layers; ++l) {
         MGEA_TRY(gemm(h->h, D, h->lw(l, BL_QKVW), M, 3 * D, D, &Sk));
         MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
@@ -160,8 +195,9 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->h, nullptr,
                                     h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, M, D, 1, st));
     }
-    // pooled = h[:, 0]  ->  pre_classifier -> ReLU -> classifier
     MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+    }
+    // pooled = h[:, 0]  ->  pre_classifier -> ReLU -> classifier (fp32 in both modes)
     MGEA_TRY(gemm(h->pooled, D, h->hw(0), B, D, D, &Sk));
     MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->hw(1), h->pooled2, D, B, D, ACT_RELU, st));
     MGEA_TRY(gemm(h->pooled2, D, h->hw(2), B, NL, D, &Sk));

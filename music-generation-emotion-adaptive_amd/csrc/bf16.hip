@@ -1,0 +1,392 @@
+// bf16 "perf mode" kernels for the prefill-only DistilBERT path (BASELINE.json configs[1]: bf16,
+// B=256, S=128): bf16 storage for weights and activations, fp32 accumulation in the MFMAs, fp32
+// LayerNorm / softmax / GELU math.  Parity mode stays fp32 (gemm_f32.hip, attn_dense.hip); these
+// kernels are validated against the oracle run on bf16-rounded weights (tests/test_gpu_bf16.py).
+//
+// * gemm_bf16_nt_kernel: C[M,N] = epi(A[M,K] @ W[N,K]^T + bias), v_mfma_f32_16x16x32_bf16,
+//   128x128x64 tiles, 4 waves (2x2, 64x64 per wave), LDS tiles [row][8 x 16 B] with the 16-B chunk
+//   XOR-swizzled by row&7 (conflict-free ds_write_b128 staging and ds_read_b128 fragments),
+//   register-staged double buffering (next tile's global loads fly under this tile's MFMAs), XCD-aware
+//   tile order, "swapped" MFMA so a lane owns 4 consecutive output columns (8-byte bf16 stores).
+// * attn_bf16_kernel: flash attention over a packed bf16 qkv buffer with an optional key mask;
+//   S^T = K Q^T keeps the query on lane&15, so the softmax is in-lane + two shuffles and the fp32
+//   accumulators, converted to bf16, ARE the B operand of O^T = V^T P^T (k-permutation shared by V^T).
+// * layernorm / embedding kernels: bf16 in/out, fp32 statistics.
+#include "common.h"
+
+namespace mgea {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = ld4(src + i);
+        bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+        *reinterpret_cast<bf16x4*>(dst + i) = o;
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+    }
+}
+int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, int lda,
+                                                          const bf16_t* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias,
+                                                          const bf16_t* __restrict__ res, bf16_t* __restrict__ C,
+                                                          int ldc, int M, int N, int K, int tiles_n) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ float4 lds[2][(BM + BN) * 8];  // 16-B chunks: [buf][row*8 + (chunk ^ (row&7))]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous tile runs
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int KT = K >> 6;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[4], rw[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            int r = m0 + row; r = r < M ? r : M - 1;
+            ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)r * lda + k0 + ch * 8);
+            int q = n0 + row; q = q < N ? q : N - 1;
+            rw[i] = *reinterpret_cast<const float4*>(W + (int64_t)q * ldw + k0 + ch * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            lds[buf][row * 8 + (ch ^ (row & 7))] = ra[i];
+            lds[buf][(BM + row) * 8 + (ch ^ (row & 7))] = rw[i];
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < KT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < KT) load_tile(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v = lds[buf][(wm * 64 + m * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                af[m] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float4 v = lds[buf][(BM + wn * 64 + n * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                wf[n] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[n][m], 0, 0, 0);
+        }
+        if (t + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i = output column 4g + r][j = output row c]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = m0 + wm * 64 + m * 16 + c;
+        if (row >= M) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = n0 + wn * 64 + n * 16 + 4 * g;
+            if (col >= N) continue;
+            float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+            if (bias) v = add4(v, ld4(bias + col));
+            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            if (EPI == BEPI_BIAS_RES) {
+                const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(res + (int64_t)row * ldc + col);
+                v = add4(v, make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]));
+            }
+            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+            *reinterpret_cast<bf16x4*>(C + (int64_t)row * ldc + col) = o;
+        }
+    }
+}
+
+int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
+                     int ldc, int M, int N, int K, int epi, hipStream_t st) {
+    MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
+                 MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
+    dim3 grid(tm * tn), block(256);
+    const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
+    bf16_t* c = (bf16_t*)C;
+    switch (epi) {
+        case BEPI_BIAS: hipLaunchKernelGGL(gemm_bf16_nt_kernel<BEPI_BIAS>, grid, block, 0, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn); break;
+        case BEPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_nt_kernel<BEPI_BIAS_GELU>, grid, block, 0, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn); break;
+        case BEPI_BIAS_RES:
+            MGEA_REQUIRE(res, MGEA_EINVAL, "bf16 gemm: residual epilogue without residual");
+            hipLaunchKernelGGL(gemm_bf16_nt_kernel<BEPI_BIAS_RES>, grid, block, 0, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn);
+            break;
+        default: MGEA_REQUIRE(false, MGEA_EINVAL, "bf16 gemm: bad epilogue %d", epi);
+    }
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over bf16 rows (fp32 statistics), in place allowed.  One wave per row, 4 rows/block.
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, bf16_t* __restrict__ y, int M,
+                                                            int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C >> 3;  // 16-byte chunks per row
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + row * C + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + i * 64 < nch)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mean) * rstd * w[ch * 8 + j] + b[ch * 8 + j]);
+            *reinterpret_cast<bf16x8*>(y + row * C + ch * 8) = o;
+        }
+    }
+}
+int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st) {
+    MGEA_REQUIRE(C % 8 == 0 && C <= 2048, MGEA_EINVAL, "bf16 layernorm: C=%d must be a multiple of 8 and <= 2048", C);
+    hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, M, C, eps);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// h[m] = LN(word[ids[m]] + pos[t]) -> bf16 (fp32 tables)
+__global__ __launch_bounds__(256) void bert_embed_ln_bf16_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
+                                                                const float* __restrict__ pos, const float* __restrict__ lnw,
+                                                                const float* __restrict__ lnb, float eps,
+                                                                bf16_t* __restrict__ h, int M, int S, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int t = (int)(row % S);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int nf4 = D >> 2;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = lane + i * 64;
+        if (f < nf4) {
+            v[i] = add4(ld4(word + (int64_t)id * D + f * 4), ld4(pos + (int64_t)t * D + f * 4));
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + i * 64 < nf4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = lane + i * 64;
+        if (f < nf4) {
+            const float4 ww = ld4(lnw + f * 4), bb = ld4(lnb + f * 4);
+            bf16x4 o = {(bf16_t)((v[i].x - mean) * rstd * ww.x + bb.x), (bf16_t)((v[i].y - mean) * rstd * ww.y + bb.y),
+                        (bf16_t)((v[i].z - mean) * rstd * ww.z + bb.z), (bf16_t)((v[i].w - mean) * rstd * ww.w + bb.w)};
+            *reinterpret_cast<bf16x4*>(h + row * D + f * 4) = o;
+        }
+    }
+}
+int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st) {
+    MGEA_REQUIRE(D % 4 == 0 && D <= 2048, MGEA_EINVAL, "bf16 embed: dim=%d must be a multiple of 4 and <= 2048", D);
+    hipLaunchKernelGGL(bert_embed_ln_bf16_kernel, dim3(ceil_div(B * S, 4)), dim3(256), 0, st, ids, word, pos, lnw, lnb, eps,
+                       (bf16_t*)h, B * S, S, D, vocab);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// CLS rows (row b*S) of a bf16 [B*S, D] matrix -> fp32 [B, D] for the small fp32 classifier head
+__global__ void gather_cls_bf16_kernel(const bf16_t* __restrict__ h, float* __restrict__ out, int S, int D) {
+    const int64_t b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[b * D + d] = (float)h[b * S * (int64_t)D + d];
+}
+int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st) {
+    hipLaunchKernelGGL(gather_cls_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, out, S, D);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Flash attention, bf16 in/out, head_dim 64.  Workgroup = 64 queries of one (b, h); 4 waves x 16.
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                       bf16_t* __restrict__ out, int T, int H, float scale) {
+    constexpr int DH = 64;
+    constexpr int VT_LD = 68;                       // bf16 elements per V^T row: 136-B pitch, conflict-free b64 reads
+    __shared__ float4 sK[64 * 8];                   // [key][8 x 16 B], chunk ^= key & 7
+    __shared__ __attribute__((aligned(16))) bf16_t sVt[DH * VT_LD];  // [d][key]
+    __shared__ int sValid[64];
+
+    const int C = H * DH;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)b * T;
+
+    int qrow = q0 + wave * 16 + c;
+    const bool q_in = qrow < T;
+    qrow = q_in ? qrow : T - 1;
+    bf16x8 qf[2];  // d = 32*ks + 8g .. +7, pre-scaled by 1/sqrt(dh) (a power of two: exact in bf16)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * 3 * C + h * DH + ks * 32 + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16_t)((float)t[j] * scale);
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, lsum = 0.f;
+
+    const int ntiles = (T + 63) >> 6;
+    for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+        const int k0 = kt0 * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // 64 keys x 8 chunks = 512 chunks of K and of V
+            const int idx = tid + i * 256, key = idx >> 3, ch = idx & 7;
+            int kr = k0 + key; kr = kr < T ? kr : T - 1;
+            const bf16_t* src = qkv + (row0 + kr) * 3 * C + h * DH + ch * 8;
+            sK[key * 8 + (ch ^ (key & 7))] = *reinterpret_cast<const float4*>(src + C);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 2 * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VT_LD + key] = v[j];   // transpose on write
+        }
+        if (tid < 64) {
+            const int kidx = k0 + tid;
+            bool ok = kidx < T;
+            if (ok && mask) ok = mask[row0 + kidx] != 0;
+            sValid[tid] = ok ? 1 : 0;
+        }
+        __syncthreads();
+
+        f32x4 sc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int key = kt * 16 + c;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float4 kv = sK[key * 8 + ((ks * 4 + g) ^ (key & 7))];
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kv), qf[ks], sc[kt], 0, 0, 0);
+            }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int4 vl = *reinterpret_cast<const int4*>(&sValid[kt * 16 + 4 * g]);
+            sc[kt][0] = vl.x ? sc[kt][0] : -INFINITY;
+            sc[kt][1] = vl.y ? sc[kt][1] : -INFINITY;
+            sc[kt][2] = vl.z ? sc[kt][2] : -INFINITY;
+            sc[kt][3] = vl.w ? sc[kt][3] : -INFINITY;
+            tmax = fmaxf(tmax, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mx, tmax);
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = (mx == -INFINITY) ? 0.f : __expf(mx - msafe);
+        float psum = 0.f;
+        bf16x8 pf[2];  // B operand of PV: k index 8g+j <-> key 32p + 4g + j (j<4), 32p + 16 + 4g + (j-4)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[kt][r] - msafe);
+                psum += p;
+                pf[kt >> 1][(kt & 1) * 4 + r] = (bf16_t)p;
+            }
+        lsum = lsum * alpha + psum;
+        mx = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha; }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* vr = sVt + (dt * 16 + c) * VT_LD + 32 * p + 4 * g;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[p], oacc[dt], 0, 0, 0);
+            }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (q_in) {
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 o = {(bf16_t)(oacc[dt][0] * inv), (bf16_t)(oacc[dt][1] * inv), (bf16_t)(oacc[dt][2] * inv), (bf16_t)(oacc[dt][3] * inv)};
+            *reinterpret_cast<bf16x4*>(out + (row0 + qrow) * C + h * DH + dt * 16 + 4 * g) = o;
+        }
+    }
+}
+
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st) {
+    MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
+    MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
+    dim3 grid(ceil_div(T, 64), H, B);
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
+                       1.0f / sqrtf((float)dh));
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+}  // namespace mgea

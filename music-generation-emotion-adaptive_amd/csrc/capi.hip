@@ -64,6 +64,29 @@ int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const i
     return launch_attn_dense(qkv_dev, lens_dev, mask_dev, out_dev, B, T, n_head, head_dim, 0, (hipStream_t)stream);
 }
 
+int mgea_op_f32_to_bf16(const float* src_dev, void* dst_dev, int64_t n, void* stream) {
+    MGEA_REQUIRE(src_dev && dst_dev && n > 0, MGEA_EINVAL, "op_f32_to_bf16: bad argument");
+    return launch_f32_to_bf16(src_dev, dst_dev, n, (hipStream_t)stream);
+}
+
+int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev, void* out_dev,
+                      int32_t M, int32_t N, int32_t K, int32_t epi, void* stream) {
+    MGEA_REQUIRE(a_dev && w_dev && out_dev, MGEA_EINVAL, "op_gemm_bf16: NULL argument");
+    return launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream);
+}
+
+int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,
+                           int32_t n_head, int32_t head_dim, void* stream) {
+    MGEA_REQUIRE(qkv_dev && out_dev, MGEA_EINVAL, "op_attention_bf16: NULL argument");
+    return launch_attn_bf16(qkv_dev, mask_dev, out_dev, B, T, n_head, head_dim, (hipStream_t)stream);
+}
+
+int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int32_t M, int32_t C,
+                           float eps, void* stream) {
+    MGEA_REQUIRE(x_dev && w_dev && b_dev && y_dev, MGEA_EINVAL, "op_layernorm_bf16: NULL argument");
+    return launch_layernorm_bf16(x_dev, w_dev, b_dev, y_dev, M, C, eps, (hipStream_t)stream);
+}
+
 /* ablation / micro-benchmark hook for the fused skinny GEMM (tools/skinny_bench.py): EPI_ACT or
  * EPI_RES on caller buffers; dbg bits skip A loads (1), W loads (2), MFMAs (4). */
 int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev, const float* lnw_dev,

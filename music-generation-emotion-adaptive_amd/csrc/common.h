@@ -131,6 +131,17 @@ int launch_gather_rows(const float* src, int ld_src, float* dst, int ld_dst, int
 int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int in_dim, int r, float scale,
                       hipStream_t st);
 
+// ---- bf16 perf-mode kernels (bf16.hip); bf16 buffers travel as void* ---------------------------
+int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st);
+// C = epi(A @ W^T + bias): epi 0 bias, 1 bias + GELU, 2 bias + residual(res, ld = ldc)
+int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
+                     int ldc, int M, int N, int K, int epi, hipStream_t st);
+int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
+int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st);
+int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st);
+
 // ---- fused skinny GEMM (decode step, M <= 64): gemm_skinny.hip --------------------------------
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
 

@@ -67,6 +67,10 @@ PROTOTYPES = {
     "mgea_op_gemm_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "mgea_op_layernorm": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
     "mgea_op_attention_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
+    "mgea_op_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_attention_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
     "mgea_op_skinny": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_sample": (C.c_int, [_P, _I32, _I32, C.POINTER(SamplerConfig), _I64, _P, _P, _P]),
 }

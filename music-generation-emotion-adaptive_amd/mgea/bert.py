@@ -31,7 +31,9 @@ class BertEngine:
     def __init__(self, state_dict: Optional[Dict], n_heads: int = 12, adapter: Optional[Dict] = None,
                  lora_alpha: float = 16.0, lora_r: Optional[int] = None, max_tokens: int = 256 * 128,
                  device="cuda:0", geometry: Optional[Dict] = None, arena: Optional[torch.Tensor] = None,
-                 ln_eps: float = 1e-12):
+                 ln_eps: float = 1e-12, dtype: str = "f32"):
+        """dtype "f32" = parity mode (exact-fp32 MFMA); "bf16" = perf mode (bf16 weights/activations,
+        fp32 accumulate, fp32 LayerNorm/softmax/GELU; the arena stays fp32 and is converted once)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -42,7 +44,9 @@ class BertEngine:
         self.num_labels = geo["num_labels"]
         self.cfg = BertConfig(vocab=geo["vocab"], max_pos=geo["max_pos"], dim=geo["dim"], n_heads=self.n_heads,
                               n_layers=geo["n_layers"], hidden=geo["hidden"], num_labels=geo["num_labels"],
-                              max_tokens=int(max_tokens), dtype=_lib.DTYPE_F32, ln_eps=ln_eps)
+                              max_tokens=int(max_tokens),
+                              dtype=_lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_F32, ln_eps=ln_eps)
+        self.dtype = dtype
         n = C.c_int32(0)
         total = C.c_int64(0)
         check(self.lib.mgea_bert_arena_layout(C.byref(self.cfg), None, C.byref(n), C.byref(total)))

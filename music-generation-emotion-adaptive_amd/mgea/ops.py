@@ -56,6 +56,41 @@ def attention(qkv: torch.Tensor, n_head: int, lens: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+              gelu: bool = False) -> torch.Tensor:
+    """bf16 perf-mode GEMM: (a [M,K] bf16) @ (w [N,K] bf16)^T + bias (fp32) [+GELU | +res (bf16)] -> bf16."""
+    lib = _lib.load()
+    a, w = _dev(a.to(torch.bfloat16)), _dev(w.to(torch.bfloat16))
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    b = None if bias is None else _dev(bias.float())
+    r = None if res is None else _dev(res.to(torch.bfloat16))
+    epi = 2 if res is not None else (1 if gelu else 0)
+    check(lib.mgea_op_gemm_bf16(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, stream_ptr()))
+    return out
+
+
+def attention_bf16(qkv: torch.Tensor, n_head: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    qkv = _dev(qkv.to(torch.bfloat16))
+    B, T, C3 = qkv.shape
+    Cd = C3 // 3
+    out = torch.empty(B, T, Cd, dtype=torch.bfloat16, device=qkv.device)
+    m32 = None if mask is None else _dev(mask.to(torch.int32))
+    check(lib.mgea_op_attention_bf16(ptr(qkv), ptr(m32), ptr(out), B, T, n_head, Cd // n_head, stream_ptr()))
+    return out
+
+
+def layernorm_bf16(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x.to(torch.bfloat16))
+    y = torch.empty_like(x)
+    check(lib.mgea_op_layernorm_bf16(ptr(x), ptr(_dev(w.float())), ptr(_dev(b.float())), ptr(y), x.shape[0], x.shape[1],
+                                     float(eps), stream_ptr()))
+    return y
+
+
 def sample(logits: torch.Tensor, temperature=1.0, top_k=50, top_p=None, seed=0, step=0, want_probs=False):
     lib = _lib.load()
     logits = _dev(logits.float())
