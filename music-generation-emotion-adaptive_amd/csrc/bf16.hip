@@ -12,6 +12,8 @@
 //   S^T = K Q^T keeps the query on lane&15, so the softmax is in-lane + two shuffles and the fp32
 //   accumulators, converted to bf16, ARE the B operand of O^T = V^T P^T (k-permutation shared by V^T).
 // * layernorm / embedding kernels: bf16 in/out, fp32 statistics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mgea {
@@ -134,10 +136,153 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large-M variant: 256 x (64*NT) tile, 8 waves (2 x 4, 128 x 16*NT per wave), BK = 64, operands go
+// HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write pass).
+// The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle is applied
+// on the SOURCE address: the lane that fills LDS chunk (row, ch') fetches global chunk ch' ^ (row&7),
+// and the fragment reads use the same involution.  Two LDS buffers: the loads of tile t+1 are issued
+// before the MFMAs of tile t and drained (vmcnt(0)) just before the barrier that ends it.
+template <int EPI, int NT>
+__global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int lda,
+                                                            const bf16_t* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias,
+                                                            const bf16_t* __restrict__ res, bf16_t* __restrict__ C,
+                                                            int ldc, int M, int N, int K, int tiles_n) {
+    constexpr int BM = 256, BN = 64 * NT;
+    constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;   // in 16-byte chunks
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int KT = K >> 6;
+
+    // per-lane source of the glds pieces: piece p covers rows 8p .. 8p+7; lane -> (row 8p + lane/8, chunk)
+    const int lr = lane >> 3, lch = (lane & 7) ^ lr;
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = m0 + (wave * 4 + i) * 8 + lr;
+        r = r < M ? r : M - 1;
+        asrc[i] = A + (int64_t)r * lda + lch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int r = n0 + (wave * NT + i) * 8 + lr;
+        r = r < N ? r : N - 1;
+        wsrc[i] = W + (int64_t)r * ldw + lch * 8;
+    }
+    auto issue = [&](int buf, int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (wave * 4 + i) * 64),
+                                             16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * STAGE + SA + (wave * NT + i) * 64),
+                                             16, 0, 0);
+    };
+
+    f32x4 acc[NT][8];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < KT; ++t) {
+        const float4* sb = lds + (t & 1) * STAGE;
+        if (t + 1 < KT) issue((t + 1) & 1, t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 v = sb[SA + (wn * 16 * NT + n * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                wf[n] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = sb[(wm * 128 + m * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(&v);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af, acc[n][m], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int row = m0 + wm * 128 + m * 16 + c;
+        if (row >= M) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = n0 + wn * 16 * NT + n * 16 + 4 * g;
+            if (col >= N) continue;
+            float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+            if (bias) v = add4(v, ld4(bias + col));
+            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            if (EPI == BEPI_BIAS_RES) {
+                const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(res + (int64_t)row * ldc + col);
+                v = add4(v, make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]));
+            }
+            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+            *reinterpret_cast<bf16x4*>(C + (int64_t)row * ldc + col) = o;
+        }
+    }
+}
+
+template <int EPI, int NT>
+static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
+                       int ldc, int M, int N, int K, hipStream_t st) {
+    constexpr int BN = 64 * NT;
+    const size_t shmem = (size_t)2 * (256 + BN) * 128;
+    static bool attr_set = false;   // one per (EPI, NT) instantiation
+    if (!attr_set) {
+        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<EPI, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, BN);
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, NT>), dim3(tm * tn), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc,
+                       M, N, K, tn);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+template <int EPI>
+static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
+                            int ldc, int M, int N, int K, hipStream_t st) {
+    // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
+    const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
+    if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    return launch_glds<EPI, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+}
+
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
                      int ldc, int M, int N, int K, int epi, hipStream_t st) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
+    if (M >= 512 && N >= 128 && !getenv("MGEA_BF16_GEMM_SMALL")) {
+        const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
+        bf16_t* c = (bf16_t*)C;
+        if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+        if (epi == BEPI_BIAS_GELU) return launch_glds_pick<BEPI_BIAS_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+        if (epi == BEPI_BIAS_RES && res) return launch_glds_pick<BEPI_BIAS_RES>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    }
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
     dim3 grid(tm * tn), block(256);
     const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;

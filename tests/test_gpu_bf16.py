@@ -79,8 +79,8 @@ def test_bert_bf16_engine_vs_golden_fp32(golden, tag):
     assert decided.any()
     assert (amax.cpu().numpy()[decided] == g["argmax"][decided]).all()
     # closer comparison: the oracle on bf16-rounded matrices isolates activation rounding
-    sdr = {k: (torch.from_numpy(v).bfloat16().float().numpy() if v.ndim == 2 and "embeddings" not in k and "classifier" not in k else v)
-           for k, v in DistilBertRef(sd, n_heads, ad).sd.items()}
-    sdr = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sdr.items()}
+    merged = DistilBertRef(sd, n_heads, ad).sd      # torch tensors, LoRA already folded
+    sdr = {k: (v.bfloat16().float() if v.ndim == 2 and "embeddings" not in k and "classifier" not in k else v)
+           for k, v in merged.items()}
     ref = DistilBertRef(sdr, n_heads).forward(ids, mask).numpy()
     assert np.abs(logits - ref).max() < TOL
