@@ -194,8 +194,18 @@ def main():
         a = prof["attn_paged"]
         if a["launches"] > 0 and a["ms"] > 0:
             ach = bytes_total / (a["ms"] * 1e-3) / 1e9
+            # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE run of this command's
+            # eager twin (profiles/README.md): mean FETCH_SIZE x 1024 x 2 (gfx950 half-count correction)
+            traffic, traffic_note = None, None
+            pmc = os.path.join(ROOT, "profiles", "r1_pmc_fetch_size_ctx512.json")
+            if os.path.exists(pmc):
+                for k, v in json.load(open(pmc)).items():
+                    if "attn_paged_kernel" in k:
+                        traffic = v["mean"] * 1024 * 2
+                        traffic_note = ("PMC window: 32 decode steps at ctx 501-532 (algorithmic 135.5 MB per launch "
+                                        "there); counters cannot be collected under hipGraph replay")
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=None, kernel="attn_paged_kernel<64>", launches=a["launches"],
+                        traffic=traffic, traffic_note=traffic_note, kernel="attn_paged_kernel<64>", launches=a["launches"],
                         avg_launch_us=a["ms"] * 1e3 / a["launches"],
                         algorithmic_bytes_per_launch=bytes_total / a["launches"],
                         step_breakdown_ms={k: round(v["ms"] / max(1, len(prof_steps)), 4) for k, v in prof.items()})

@@ -42,6 +42,16 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2 };
 
+// erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, one v_exp + 5 fma): the
+// result is rounded to bf16 (2^-9) anyway; libm erff costs ~3x more VALU per element.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = 1.0f / (1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ W, int ldw,
@@ -143,15 +153,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
 // on the SOURCE address: the lane that fills LDS chunk (row, ch') fetches global chunk ch' ^ (row&7),
 // and the fragment reads use the same involution.  Two LDS buffers: the loads of tile t+1 are issued
 // before the MFMAs of tile t and drained (vmcnt(0)) just before the barrier that ends it.
-template <int EPI, int NT>
-__global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int lda,
+// WMW = waves along M (each 128 rows): WMW = 2 -> 256-row tile, 8 waves, one workgroup per CU;
+// WMW = 1 -> 128-row tile, 4 waves, 64 KB of LDS, two workgroups per CU whose barriers interleave.
+template <int EPI, int NT, int WMW>
+__global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int lda,
                                                             const bf16_t* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias,
                                                             const bf16_t* __restrict__ res, bf16_t* __restrict__ C,
                                                             int ldc, int M, int N, int K, int tiles_n) {
-    constexpr int BM = 256, BN = 64 * NT;
+    constexpr int BM = 128 * WMW, BN = 64 * NT, NTHR = 256 * WMW;
+    constexpr int WPW = (BN / 8) / (4 * WMW);           // W pieces (8 rows x 128 B) per wave per tile
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;   // in 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE]
+    const int dbg = tiles_n >> 16;   // ablation bits from MGEA_BF16_GEMM_DBG (0 in production)
+    tiles_n &= 0xffff;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __res
     // per-lane source of the glds pieces: piece p covers rows 8p .. 8p+7; lane -> (row 8p + lane/8, chunk)
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
     const bf16_t* asrc[4];
-    const bf16_t* wsrc[NT];
+    const bf16_t* wsrc[WPW];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int r = m0 + (wave * 4 + i) * 8 + lr;
@@ -174,8 +189,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __res
         asrc[i] = A + (int64_t)r * lda + lch * 8;
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        int r = n0 + (wave * NT + i) * 8 + lr;
+    for (int i = 0; i < WPW; ++i) {
+        int r = n0 + (wave * WPW + i) * 8 + lr;
         r = r < N ? r : N - 1;
         wsrc[i] = W + (int64_t)r * ldw + lch * 8;
     }
@@ -187,9 +202,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __res
                                              (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (wave * 4 + i) * 64),
                                              16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < WPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(lds + buf * STAGE + SA + (wave * NT + i) * 64),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * STAGE + SA + (wave * WPW + i) * 64),
                                              16, 0, 0);
     };
 
@@ -199,12 +214,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __res
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NS-deep LDS ring (3 stages of 48 KB for the 256x128 tile, 2 of 64 KB for 256x256): NS-1 tiles are
+    // in flight while one is consumed.  Counted vmcnt + raw s_barrier: a __syncthreads() would drain
+    // the LDS-DMA queue (vmcnt(0)) at every tile.  RAW: each wave waits for ITS pieces of tile t+1,
+    // then the barrier makes all pieces visible before iteration t+1 reads them.  WAR: the buffer
+    // re-filled in iteration t was last read in iteration t-1, behind that iteration's barrier.
+    constexpr int NS = (NT == 2 && WMW == 2) ? 3 : 2;
+    constexpr int PER_TILE = 4 + WPW;             // glds instructions per wave per tile
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue(s, s);
+    if (KT > NS - 2 && NS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = NS - 1;                     // ring slots of tile t and of tile t + NS - 1
     for (int t = 0; t < KT; ++t) {
-        const float4* sb = lds + (t & 1) * STAGE;
-        if (t + 1 < KT) issue((t + 1) & 1, t + 1);
+        const float4* sb = lds + cur * STAGE;
+        const bool more = t + NS - 1 < KT;
+        if (more && !(dbg & 1)) issue(nxt, t + NS - 1);
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+        if (dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); continue; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[NT];
@@ -221,44 +251,67 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(const bf16_t* __res
                 for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af, acc[n][m], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // tile t+1 must have landed; the tiles issued after it (NS-2 of them) may stay in flight
+        if (more && NS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
+    // Epilogue through LDS (the operand ring is free now): the MFMA layout gives each lane 4 columns
+    // of one row (8-byte pieces, 16 rows per instruction); staged as a [256][BN] bf16 tile and
+    // streamed out as whole rows, 16 bytes per lane -> full-line stores and residual reads.
+    constexpr int PITCH = BN * 2 + 16;            // bytes; +16 keeps 16-B alignment and staggers banks
+    unsigned char* sC = reinterpret_cast<unsigned char*>(lds);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // every wave is done reading the last operand tile
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const int row = m0 + wm * 128 + m * 16 + c;
-        if (row >= M) continue;
+        const int lrow = wm * 128 + m * 16 + c;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int col = n0 + wn * 16 * NT + n * 16 + 4 * g;
-            if (col >= N) continue;
+            const int lcol = wn * 16 * NT + n * 16 + 4 * g;
             float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
-            if (bias) v = add4(v, ld4(bias + col));
-            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-            if (EPI == BEPI_BIAS_RES) {
-                const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(res + (int64_t)row * ldc + col);
-                v = add4(v, make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]));
-            }
+            if (bias && n0 + lcol < N) v = add4(v, ld4(bias + n0 + lcol));
+            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
             bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-            *reinterpret_cast<bf16x4*>(C + (int64_t)row * ldc + col) = o;
+            *reinterpret_cast<bf16x4*>(sC + lrow * PITCH + lcol * 2) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                   // 16-byte chunks per tile row
+#pragma unroll
+    for (int i = 0; i < BM * CPR / NTHR; ++i) {
+        const int id = tid + i * NTHR, lrow = id / CPR, ch = id % CPR;
+        const int row = m0 + lrow, col = n0 + ch * 8;
+        if (row < M && col < N) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + lrow * PITCH + ch * 16);
+            if (EPI == BEPI_BIAS_RES) {
+                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
+            }
+            *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
         }
     }
 }
 
-template <int EPI, int NT>
+template <int EPI, int NT, int WMW>
 static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
                        int ldc, int M, int N, int K, hipStream_t st) {
-    constexpr int BN = 64 * NT;
-    const size_t shmem = (size_t)2 * (256 + BN) * 128;
-    static bool attr_set = false;   // one per (EPI, NT) instantiation
+    constexpr int BM = 128 * WMW, BN = 64 * NT;
+    constexpr int NS = (NT == 2 && WMW == 2) ? 3 : 2;
+    constexpr size_t ring = (size_t)NS * (BM + BN) * 128, stage_c = (size_t)BM * (BN * 2 + 16);
+    const size_t shmem = ring > stage_c ? ring : stage_c;      // 64 KB .. 144 KB of the 160 KB LDS
+    static bool attr_set = false;   // one per instantiation
     if (!attr_set) {
-        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<EPI, NT>),
+        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<EPI, NT, WMW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr_set = true;
     }
-    const int tm = ceil_div(M, 256), tn = ceil_div(N, BN);
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, NT>), dim3(tm * tn), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc,
-                       M, N, K, tn);
+    const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
+    const char* e = getenv("MGEA_BF16_GEMM_DBG");   // tools/gemm_bf16_bench.py ablations only
+    const int dbg = e ? (atoi(e) & 3) : 0;
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, NT, WMW>), dim3(tm * tn), dim3(256 * WMW), shmem, st, a, lda, w, ldw, bias,
+                       r, c, ldc, M, N, K, tn | (dbg << 16));
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -266,17 +319,23 @@ static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const
 template <int EPI>
 static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
                             int ldc, int M, int N, int K, hipStream_t st) {
+    const char* e = getenv("MGEA_BF16_GEMM_TILE");   // 1: 128x128 / 2: 256x128 / 3: 256x256 (tools/gemm_bf16_bench.py)
+    const int force = e ? atoi(e) : 0;
+    if (force == 1) return launch_glds<EPI, 2, 1>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    if (force == 2) return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    if (force == 3) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
-    if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
-    return launch_glds<EPI, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
 }
 
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
                      int ldc, int M, int N, int K, int epi, hipStream_t st) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
-    if (M >= 512 && N >= 128 && !getenv("MGEA_BF16_GEMM_SMALL")) {
+    if (const char* ld = getenv("MGEA_BF16_GEMM_LD")) lda = ldw = atoi(ld);   // timing experiments only (wrong results)
+    if (M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && !getenv("MGEA_BF16_GEMM_SMALL")) {
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
         bf16_t* c = (bf16_t*)C;
         if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
