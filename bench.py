@@ -130,10 +130,16 @@ def main():
     from mgea.decoder import DecoderEngine, arena_layout
     import torch.distributed as dist
 
-    rank, world, local = mdist.init_from_env("nccl")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    # production: "nccl" (= RCCL over xGMI), one rank per GPU.  MGEA_DIST_BACKEND=gloo rehearses the
+    # N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices round-robin).
+    backend = os.environ.get("MGEA_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend != "nccl":
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev))
+    rank, world, local = mdist.init_from_env(backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -171,10 +177,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = mdist.all_reduce_max(dt, device)
     tokens = world * args.steps * B * n_steps
     value = tokens / dt
 

@@ -34,8 +34,24 @@ def init_from_env(backend: Optional[str] = None):
 def broadcast_arena(arena: torch.Tensor, src: int = 0) -> torch.Tensor:
     """One collective for every weight: the arena is a single contiguous fp32 buffer."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(arena, src=src)
+        if arena.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal of the N > 1 path on a 1-GPU box (several ranks share the card, RCCL refuses
+            # that): stage through the host.  Production is backend "nccl" = RCCL over xGMI.
+            host = arena.cpu()
+            dist.broadcast(host, src=src)
+            arena.copy_(host)
+        else:
+            dist.broadcast(arena, src=src)
     return arena
+
+
+def all_reduce_max(value: float, device) -> float:
+    """max over ranks of a host scalar (bench.py's timing reduction)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> range:
