@@ -22,9 +22,16 @@ def create_app(model, seq_len: int, temperature: float = 1.0, top_k: int = 50):
 
     app = FastAPI()
     app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_methods=["*"], allow_headers=["*"])
+    try:   # the reference reads a multipart form field (api_cache.py:187); that needs python-multipart
+        import multipart  # noqa: F401
+        prompt_param = Form(...)
+    except ImportError:   # absent on the offline box: same endpoint, `prompt` as a query parameter
+        from fastapi import Query
+        prompt_param = Query(...)
+    app.state.prompt_in = "form" if prompt_param.__class__.__name__ == "Form" else "query"
 
     @app.post("/generate")
-    def generate_music(prompt: str = Form(...)):
+    def generate_music(prompt: str = prompt_param):
         label = inference.predict(prompt)                                     # api_cache.py:189
         mapping = EATS.get_music_params(label)                                # :190
         bpm_tok = gen.closest_bpm_token(mapping["bpm"])                       # :194

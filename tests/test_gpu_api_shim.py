@@ -33,9 +33,12 @@ def test_generate_endpoint_end_to_end(golden):
     bsd = synth.distilbert_state_dict(61, len(vmap), 64, 128, 2, 512)
     inference.configure(WordPieceTokenizer(vmap), BertEngine(bsd, n_heads=2, adapter=synth.lora_adapter(61, 128, 2), max_tokens=64))
 
-    client = TestClient(create_app(model, seq_len=32, temperature=1.0, top_k=1))
+    app = create_app(model, seq_len=32, temperature=1.0, top_k=1)
+    client = TestClient(app)
+    text = "i am walking down a road and i see a rainbow. i love life."
+    kw = {"data": {"prompt": text}} if app.state.prompt_in == "form" else {"params": {"prompt": text}}
     random.seed(11)
-    r = client.post("/generate", data={"prompt": "i am walking down a road and i see a rainbow. i love life."})
+    r = client.post("/generate", **kw)
     assert r.status_code == 200 and r.headers["content-type"].startswith("audio/midi")
     assert r.content[:4] == b"MThd" and int(r.headers["x-generated-tokens"]) == 32
     label = r.headers["x-emotion"]
@@ -50,4 +53,4 @@ def test_generate_endpoint_end_to_end(golden):
     toks = gen.sample_kvcache(model, prompt, max_len=32, top_k=1)
     want = DecoderRef(sd, n_head).generate_greedy([[gen.tok2id[t] for t in prompt]], 32 - len(prompt))[0]
     assert [gen.tok2id[t] for t in toks] == want
-    assert client.post("/generate", data={}).status_code == 422          # FastAPI's own validation, as in the reference
+    assert client.post("/generate").status_code == 422          # FastAPI's own validation, as in the reference
