@@ -37,27 +37,10 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     const int t = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_new = lens ? lens[b] : T;
     const int64_t m = (int64_t)b * T + t;
-    auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d) : out + m * C + h * DH + d; };
-    if (t >= n_new) {  // padded query row: defined output, never used
-        if (threadIdx.x < DH) *optr(threadIdx.x) = 0.f;
-        return;
-    }
-    const int len = ctx_len[b] + n_new;  // tokens visible to this query (whole cache, no mask)
-    const int npages = (len + 63) >> 6;
-
-    const float* qp = qkv + m * 3 * C + h * DH;
-    float q[DH];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) q[d] = qp[d] * scale;  // 1/sqrt(64) etc.: power-of-two scales are exact
-
     const int64_t pf = pool.page_floats();
     const float* lbase = pool.base + layer * pool.layer_stride;
     const int g = lane / NCH, c = lane % NCH;
-
-    float mx = -INFINITY, lsum = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // Software pipeline over this wave's pages: while QK^T consumes K(page) the V(page) loads are in
     // flight, and while PV consumes V(page) the K(next page) loads are -- each wave keeps 16 KiB
@@ -72,7 +55,29 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NCH; ++i) kk[i] = ldnt4(kpage + (i * 64 + lane) * 4);
     };
-    if (wave < npages) load_k(wave);
+    // The first K tile is requested before anything else is known: its page index depends only on the
+    // wave id, so the page-table -> K round trips overlap the ctx_len / q fetches (the kernel's fixed
+    // latency is what short contexts pay).  A wave beyond the row's pages reads a reserved (zeroed or
+    // stale but mapped) page and drops it.
+    load_k(wave < max_pages ? wave : max_pages - 1);
+
+    const int n_new = lens ? lens[b] : T;
+    auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d) : out + m * C + h * DH + d; };
+    if (t >= n_new) {  // padded query row: defined output, never used
+        if (threadIdx.x < DH) *optr(threadIdx.x) = 0.f;
+        return;
+    }
+    const int len = ctx_len[b] + n_new;  // tokens visible to this query (whole cache, no mask)
+    const int npages = (len + 63) >> 6;
+
+    const float* qp = qkv + m * 3 * C + h * DH;
+    float q[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) q[d] = qp[d] * scale;  // 1/sqrt(64) etc.: power-of-two scales are exact
+
+    float mx = -INFINITY, lsum = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
     for (int pg = wave; pg < npages; pg += 4) {
         const float* vpage = page_base(pg, 1);
 #pragma unroll

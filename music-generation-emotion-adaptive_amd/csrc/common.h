@@ -170,6 +170,9 @@ int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* c
                        int absolute_pos, hipStream_t st);
 int launch_argmax_advance(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
                           int B, hipStream_t st);
+int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
+                                const float* tok_emb, const float* pos_emb, float* x, float* stats, int B, int C, int vocab,
+                                int pos_rows, int absolute_pos, hipStream_t st);
 
 }  // namespace mgea
 

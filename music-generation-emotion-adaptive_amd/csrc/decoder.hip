@@ -322,27 +322,39 @@ StepState step_state(mgea_decoder* h, int eos) {
 }
 
 // one decode step on cur_ids (T = 1); logits_out optional
-int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* logits_out, hipStream_t st) {
+// primed: x already holds the embedding (+ LN statistics) of cur_ids -- generate() keeps that invariant by
+// fusing the next step's embedding into this step's tail, so a replayed step is 32 launches.
+int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* logits_out, hipStream_t st,
+                 bool primed = false) {
     const auto& c = h->cfg;
     const int C = c.d_model, V = c.vocab;
     const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
     const bool greedy = sc.top_k == 1;
     if (fused_ok(h, B)) {
-        // 33 launches: embed, 6 x (qkv, attention, out-proj, fc1, fc2), head (+ per-tile argmax), finalize
-        PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1,
-                                          C, V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+        // [embed,] 6 x (qkv, attention, out-proj, fc1, fc2), head (+ per-tile argmax), finalize [+ next embed]
+        const int abs_pos = c.pos_mode == MGEA_POS_ABSOLUTE;
+        if (!primed)
+            PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1,
+                                              C, V, c.seq_len, abs_pos, st));
         MGEA_TRY(run_blocks_fused(h, B, 1, nullptr, true, st));
         SkinnyArgs a{};
         a.M = B; a.A = h->x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
         a.out = logits_out ? logits_out : (greedy ? nullptr : h->logits);
         a.ldo = V; a.pmax_val = h->pmax_val; a.pmax_idx = h->pmax_idx;
         PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
-        if (greedy) {
+        if (greedy && primed) {
+            PROF(PC_SAMPLE, launch_argmax_advance_embed(h->pmax_val, h->pmax_idx, ceil_div(V, 16), step_state(h, sc.eos_id),
+                                                        h->sampled, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, C, V,
+                                                        c.seq_len, abs_pos, st));
+        } else if (greedy) {
             PROF(PC_SAMPLE, launch_argmax_advance(h->pmax_val, h->pmax_idx, ceil_div(V, 16), step_state(h, sc.eos_id),
                                                   h->sampled, B, st));
         } else {
             PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
             PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, sc.eos_id), B, st));
+            if (primed)
+                PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B,
+                                                  1, C, V, c.seq_len, abs_pos, st));
         }
         return MGEA_OK;
     }
@@ -580,7 +592,7 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
     if (!h->no_graph && (!h->gexec || h->g_batch != B || !same_sampler(h->g_samp, *s))) {
         drop_graph(h);
         MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_step(h, B, *s, nullptr, st);
+        const int rc = enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B));
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(st, &g);
         if (rc != MGEA_OK) {
@@ -596,16 +608,19 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
         (void)hipGraphGetNodes(g, nullptr, &nn);
         h->counters[0] = (int64_t)nn;
     }
+    if (fused_ok(h, B))   // prime x with the embedding of the re-fed last prompt token (api_cache.py:167)
+        MGEA_TRY(launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1, c.d_model,
+                                    c.vocab, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
     int launched = 0;
     int32_t host_done = 0;
     for (int i = 0; i < n_steps; ++i) {
         if (h->prof_stride > 0 && (i % h->prof_stride) == h->prof_stride / 2) {
             h->prof_now = true;  // this step runs eagerly with HIP events around every launch
-            const int rc = enqueue_step(h, B, *s, nullptr, st);
+            const int rc = enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B));
             h->prof_now = false;
             MGEA_TRY(rc);
         } else if (h->no_graph) {
-            MGEA_TRY(enqueue_step(h, B, *s, nullptr, st));
+            MGEA_TRY(enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B)));
         } else {
             MGEA_CHECK_HIP(hipGraphLaunch(h->gexec, st));
         }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wf[2][2] = {}, af[2][MT][2] = {}, gf[2][2], bf[2][2];
+    float4 wf[2][2] = {}, af[2][MT][2] = {}, gf[2][2] = {}, bf[2][2] = {};
     auto load_chunk = [&](int buf, int ch) {
         const int ko = ch * 32;
         if (!(a.dbg & 2)) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
                 af[buf][mt][1] = ld4(arow[mt] + (int64_t)ch * 64 * 32 + 4);
             }
         }
-        if (LN) {
+        if (LN && !(a.dbg & 8)) {
             gf[buf][0] = ld4(gptr + ko); gf[buf][1] = ld4(gptr + ko + 4);
             bf[buf][0] = ld4(bptr + ko); bf[buf][1] = ld4(bptr + ko + 4);
         }
@@ -388,6 +388,106 @@ __global__ __launch_bounds__(64) void argmax_advance_kernel(const float* __restr
         if (s.ids_out && step < s.n_steps) s.ids_out[(int64_t)b * s.n_steps + step] = out;
         s.row_step[b] = step + 1;
     }
+}
+
+// Same finalize fused with the NEXT step's embedding (generate() keeps x "primed"): one launch less
+// per decode step.  256 threads per row: partial-argmax reduce, bookkeeping by thread 0, then
+// x[row] = tok_emb[token] + pos_emb[pos] (k-tiled) and its LayerNorm partial statistics.
+__global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* __restrict__ pval,
+                                                                  const int32_t* __restrict__ pidx, int n_tiles,
+                                                                  StepState s, int32_t* __restrict__ sampled,
+                                                                  const float* __restrict__ tok_emb,
+                                                                  const float* __restrict__ pos_emb, float* __restrict__ x,
+                                                                  float* __restrict__ stats, int C, int vocab, int pos_rows,
+                                                                  int absolute_pos) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_tok, s_pos;
+    __shared__ float redv[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n_tiles; i += 256) {
+        const float v = pval[(int64_t)b * n_tiles + i];
+        const int ix = pidx[(int64_t)b * n_tiles + i];
+        if (v > best || (v == best && ix < bi)) { best = v; bi = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        const int tok = bi == 0x7fffffff ? 0 : bi;
+        sampled[b] = tok;
+        const int step = s.row_step[b];
+        int out = -1, fed = s.cur_ids[b], len = s.ctx_len[b];
+        if (!s.done[b]) {
+            out = tok;
+            fed = tok;
+            s.cur_ids[b] = tok;
+            len += 1;
+            s.ctx_len[b] = len;
+            if (tok == s.eos_id) {
+                s.done[b] = 1;
+                atomicAdd(s.n_done, 1);
+            }
+        }
+        if (s.ids_out && step < s.n_steps) s.ids_out[(int64_t)b * s.n_steps + step] = out;
+        s.row_step[b] = step + 1;
+        s_tok = fed < 0 ? 0 : (fed >= vocab ? vocab - 1 : fed);
+        int pos = absolute_pos ? len : 0;   // reference: a decode step adds pos_emb[:1] = row 0 (api_cache.py:99)
+        s_pos = pos < pos_rows ? pos : pos_rows - 1;
+    }
+    __syncthreads();
+    const int id = s_tok, pos = s_pos;
+    const int nf4 = C >> 2;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nf4) {
+            v[i] = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
+            st4(x + tiled_off(b, f * 4), v[i]);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    auto bsum = [&](float val) {
+        val = wave_sum(val);
+        __syncthreads();
+        if (lane == 0) redv[wave] = val;
+        __syncthreads();
+        return (redv[0] + redv[1]) + (redv[2] + redv[3]);
+    };
+    const float mean = bsum(sum) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256;
+        if (f < nf4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float m2 = bsum(q);
+    if (tid == 0) *reinterpret_cast<float2*>(stats + (int64_t)b * 2) = make_float2(mean, m2);
+}
+
+int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
+                                const float* tok_emb, const float* pos_emb, float* x, float* stats, int B, int C, int vocab,
+                                int pos_rows, int absolute_pos, hipStream_t st) {
+    MGEA_REQUIRE(B <= 64 && C % 4 == 0 && C <= 4096, MGEA_EINVAL, "argmax+embed: bad shape");
+    hipLaunchKernelGGL(argmax_advance_embed_kernel, dim3(B), dim3(256), 0, st, pval, pidx, n_tiles, s, sampled, tok_emb, pos_emb,
+                       x, stats, C, vocab, pos_rows, absolute_pos);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
 }
 
 int launch_argmax_advance(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,

@@ -41,20 +41,7 @@ def run(name, epi, N, K, ln, dbg, iters=400):
           f"{e0.elapsed_time(e1) / (iters // 50 * 50) * 1e3:7.2f} us/launch", flush=True)
 
 
-def sweep(name, epi, N, K, ln):
-    for mt in (1, 2, 4):
-        for nw in (4, 8, 16):
-            if (K // 32) % nw or (ln and mt == 4 and nw > 8) or (ln and nw * 64 < 64 * mt):
-                continue
-            for dbg in (0, 7):
-                try:
-                    run(f"{name} nw={nw}", epi, N, K, ln, dbg | (mt << 8) | (nw << 12))
-                except RuntimeError as e:
-                    print(name, mt, nw, "skipped:", e)
-
-
-sweep("qkv-like (ACT, LN)", 2, 1536, 512, True)
-sweep("fc1 (ACT, LN)", 2, 2048, 512, True)
-sweep("out-proj (RES)", 1, 512, 512, False)
-sweep("fc2 (RES)", 1, 512, 2048, False)
-sweep("head-like (ACT)", 2, 8320, 512, False)
+for dbg in (0, 8, 7):
+    d = dbg | (2 << 8) | (8 << 12)
+    run("qkv-like (ACT, LN) nw=8", 2, 1536, 512, True, d)
+    run("fc1 (ACT, LN) nw=8", 2, 2048, 512, True, d)
