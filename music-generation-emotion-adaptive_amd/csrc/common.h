@@ -165,6 +165,7 @@ struct SkinnyArgs {
     int dbg;                   // ablation bits for tools/skinny_bench.py (0 in production)
 };
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
+int skinny_logits_tiles(int M, int N);
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
                        int absolute_pos, hipStream_t st);

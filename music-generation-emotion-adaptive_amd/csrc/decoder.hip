@@ -262,7 +262,8 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
 // Fused path for M = B*T <= 64 rows in the KV-cache block mode: 5 launches per layer
 // (gemm_skinny.hip); x carries per-row LayerNorm partial statistics between kernels.
 bool fused_ok(const mgea_decoder* h, int M) {
-    return h->cfg.block_mode == MGEA_BLOCK_PRELN_GELU && M <= 64 && (h->cfg.d_model % 128) == 0 && !h->force_unfused;
+    return h->cfg.block_mode == MGEA_BLOCK_PRELN_GELU && M <= 64 && (h->cfg.d_model % 128) == 0 && h->cfg.d_model <= 1024 &&
+           !h->force_unfused;
 }
 
 int run_blocks_fused(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
@@ -343,11 +344,11 @@ int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* l
         a.ldo = V; a.pmax_val = h->pmax_val; a.pmax_idx = h->pmax_idx;
         PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
         if (greedy && primed) {
-            PROF(PC_SAMPLE, launch_argmax_advance_embed(h->pmax_val, h->pmax_idx, ceil_div(V, 16), step_state(h, sc.eos_id),
+            PROF(PC_SAMPLE, launch_argmax_advance_embed(h->pmax_val, h->pmax_idx, skinny_logits_tiles(B, V), step_state(h, sc.eos_id),
                                                         h->sampled, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, C, V,
                                                         c.seq_len, abs_pos, st));
         } else if (greedy) {
-            PROF(PC_SAMPLE, launch_argmax_advance(h->pmax_val, h->pmax_idx, ceil_div(V, 16), step_state(h, sc.eos_id),
+            PROF(PC_SAMPLE, launch_argmax_advance(h->pmax_val, h->pmax_idx, skinny_logits_tiles(B, V), step_state(h, sc.eos_id),
                                                   h->sampled, B, st));
         } else {
             PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));

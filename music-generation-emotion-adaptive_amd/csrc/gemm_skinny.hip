@@ -25,18 +25,19 @@
 
 namespace mgea {
 
-template <int EPI, bool LN, int MT>
-__global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
-    constexpr int ROWS = 16 * MT;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][16] (+ 2*ROWS floats of LN stats)
-    float* s_mean = red + (blockDim.x >> 6) * ROWS * 16;           // all LDS in ONE array (16-B aligned carve)
+// NT = 16-column tiles per workgroup (2 only for the LM head: 64 rows x 32 columns halves the A bytes per output)
+template <int EPI, bool LN, int MT, int NT>
+__global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
+    constexpr int ROWS = 16 * MT, COLS = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ 2*ROWS floats of LN stats)
+    float* s_mean = red + (blockDim.x >> 6) * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * COLS;
     const int m0 = blockIdx.y * ROWS;
     const int kw = a.K / NW, kbeg = wave * kw;
     const int nchunk = kw >> 5;
@@ -45,22 +46,31 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
     const float* arow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) arow[mt] = a.A + tiled_off(m0 + mt * 16 + c, kbeg + 8 * g);
-    int wr = n0 + c;
-    wr = wr < a.N ? wr : a.N - 1;
-    const float* wrow = a.W + (int64_t)wr * a.K + kbeg + 8 * g;
+    const float* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int wr = n0 + nt * 16 + c;
+        wr = wr < a.N ? wr : a.N - 1;
+        wrow[nt] = a.W + (int64_t)wr * a.K + kbeg + 8 * g;
+    }
     const float* gptr = a.lnw + kbeg + 8 * g;
     const float* bptr = a.lnb + kbeg + 8 * g;
 
-    f32x4 acc[MT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wf[2][2] = {}, af[2][MT][2] = {}, gf[2][2] = {}, bf[2][2] = {};
+    float4 wf[2][NT][2] = {}, af[2][MT][2] = {}, gf[2][2] = {}, bf[2][2] = {};
     auto load_chunk = [&](int buf, int ch) {
         const int ko = ch * 32;
         if (!(a.dbg & 2)) {
-            wf[buf][0] = ld4(wrow + ko);
-            wf[buf][1] = ld4(wrow + ko + 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wf[buf][nt][0] = ld4(wrow[nt] + ko);
+                wf[buf][nt][1] = ld4(wrow[nt] + ko + 4);
+            }
         }
         if (!(a.dbg & 1)) {
 #pragma unroll
@@ -79,7 +89,6 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
         if (a.dbg & 4) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 w4 = wf[buf][h];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float4 x = af[buf][mt][h];
@@ -90,10 +99,14 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
                     x.z = (x.z - mu[mt]) * rs[mt] * gg.z + bb.z;
                     x.w = (x.w - mu[mt]) * rs[mt] * gg.w + bb.w;
                 }
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x.x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x.y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x.z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x.w, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 w4 = wf[buf][nt][h];
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x.x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x.y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x.z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x.w, acc[mt][nt], 0, 0, 0);
+                }
             }
         }
     };
@@ -109,17 +122,26 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
             //   mean = average of the tile means,  M2 = sum M2_t + part_cnt * sum (mean_t - mean)^2
             const bool ok = row < a.M;
             const float* sp = a.stats_in + ((int64_t)(ok ? row : 0) * a.n_part) * 2;
+            // all (<= 16 per thread, n_part <= 64) partials are requested at once: a rolled loop would
+            // serialise one L2 round trip per partial (measured +3 us per LN kernel)
+            float2 part[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int p = q + 4 * i;
+                part[i] = p < a.n_part ? *reinterpret_cast<const float2*>(sp + 2 * p) : make_float2(0.f, 0.f);
+            }
             float sm = 0.f;
-            for (int p = q; p < a.n_part; p += 4) sm += sp[2 * p];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm += part[i].x;
             sm += __shfl_xor(sm, 1, 64);
             sm += __shfl_xor(sm, 2, 64);
             const float mean = sm * (1.0f / (float)a.n_part);
             const float cnt = (float)a.part_cnt;
             float m2 = 0.f;
-            for (int p = q; p < a.n_part; p += 4) {
-                const float2 s = *reinterpret_cast<const float2*>(sp + 2 * p);
-                const float d = s.x - mean;
-                m2 += s.y + cnt * d * d;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float d = part[i].x - mean;
+                m2 += (q + 4 * i < a.n_part) ? part[i].y + cnt * d * d : 0.f;
             }
             m2 += __shfl_xor(m2, 1, 64);
             m2 += __shfl_xor(m2, 2, 64);
@@ -144,16 +166,26 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
     // partial tile of this wave -> LDS: D[i = column 4g + r][j = row c]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-        *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * 16 + 4 * g]) =
-            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * COLS + nt * 16 + 4 * g]) =
+                make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
     __syncthreads();
 
-    // epilogue: thread t -> local row t >> 2, columns n0 + 4*(t & 3) .. +3
-    for (int t = tid; t < ROWS * 4; t += blockDim.x) {
-        const int lr = t >> 2, q = t & 3, row = m0 + lr;
+    // epilogue: thread t -> local row t / (4*NT), columns n0 + 4*(t % (4*NT)) .. +3
+    for (int t = tid; t < ROWS * 4 * NT; t += blockDim.x) {
+        const int lr = t / (4 * NT), q = t % (4 * NT), row = m0 + lr;
         const int n = n0 + 4 * q;
-        float4 v = *reinterpret_cast<const float4*>(&red[lr * 16 + 4 * q]);
-        for (int w = 1; w < NW; ++w) v = add4(v, *reinterpret_cast<const float4*>(&red[(w * ROWS + lr) * 16 + 4 * q]));
+        // the NW partial tiles are read at once (a rolled loop serialises one LDS round trip per wave)
+        // and summed in wave order -> deterministic
+        float4 pv[8];   // NW <= 8 (pick_waves)
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            pv[w] = w < NW ? *reinterpret_cast<const float4*>(&red[(w * ROWS + lr) * COLS + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = pv[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+            if (w < NW) v = add4(v, pv[w]);
         const bool row_ok = row < a.M;
         if (EPI != EPI_LOGITS) {
             // N % 16 == 0 for these epilogues (checked on the host)
@@ -179,8 +211,8 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
             float m2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
             m2 += __shfl_xor(m2, 1, 64);
             m2 += __shfl_xor(m2, 2, 64);
-            if (q == 0 && row_ok && a.stats_out)
-                *reinterpret_cast<float2*>(a.stats_out + ((int64_t)row * (a.N >> 4) + blockIdx.x) * 2) = make_float2(mean, m2);
+            if ((q & 3) == 0 && row_ok && a.stats_out)
+                *reinterpret_cast<float2*>(a.stats_out + ((int64_t)row * (a.N >> 4) + blockIdx.x * NT + (q >> 2)) * 2) = make_float2(mean, m2);
         }
         if (EPI == EPI_QKV) {
             const int b = row_ok ? row / a.T : 0, tt = row_ok ? row % a.T : 0;
@@ -216,7 +248,7 @@ __global__ __launch_bounds__((LN && MT == 4) ? 512 : 1024) void gemm_skinny_kern
                 }
             }
 #pragma unroll
-            for (int o = 1; o <= 2; o <<= 1) {
+            for (int o = 1; o < 4 * NT; o <<= 1) {
                 const float ov = __shfl_xor(best, o, 64);
                 const int oi = __shfl_xor(bi, o, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
@@ -249,13 +281,13 @@ static int pick_waves(int K, bool ln, int mt) {
     return 1;
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int NT = 1>
 static int launch_skinny_mt(const SkinnyArgs& a, int nw, hipStream_t st) {
     const bool ln = a.lnw != nullptr;
-    dim3 grid(ceil_div(a.N, 16), ceil_div(a.M, 16 * MT)), block(64 * nw);
-    const size_t shmem = ((size_t)nw * 16 * MT * 16 + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
-    if (ln) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT>), grid, block, shmem, st, a);
-    else    hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT>), grid, block, shmem, st, a);
+    dim3 grid(ceil_div(a.N, 16 * NT), ceil_div(a.M, 16 * MT)), block(64 * nw);
+    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
+    if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
+    else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -266,10 +298,16 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
+    if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !(a.dbg >> 8)) {
+        // LM head: 64 rows x 32 columns per workgroup (one per CU at V = 8324), W fetched from HBM once
+        const int nw_head = pick_waves(a.K, false, 2);
+        return launch_skinny_mt<EPI_LOGITS, 2, 2>(a, nw_head, st);
+    }
     const int mt = ((a.dbg >> 8) & 15) ? ((a.dbg >> 8) & 15) : pick_mt(a.M, a.N);
     int nw = pick_waves(a.K, ln, mt);
     if ((a.dbg >> 12) & 31) nw = (a.dbg >> 12) & 31;  // tools/skinny_bench.py override
-    MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= ((ln && mt == 4) ? 8 : 16), MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
+    MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= 8, MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
+    MGEA_REQUIRE(!ln || a.n_part <= 64, MGEA_EINVAL, "skinny gemm: more than 64 LayerNorm partials per row (%d)", a.n_part);
     MGEA_REQUIRE(!ln || nw * 64 >= 16 * mt * 4, MGEA_EINVAL, "skinny gemm: LN prologue needs K %% 128 == 0 (K=%d)", a.K);
     switch (mt) {
         case 1: return launch_skinny_mt<EPI, 1>(a, nw, st);
@@ -279,6 +317,9 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     set_error("skinny gemm: bad row-tile count %d", mt);
     return MGEA_EINVAL;
 }
+
+// number of per-row partial (max, argmax) entries the LOGITS epilogue writes = its grid.x
+int skinny_logits_tiles(int M, int N) { return (M > 32 && N >= 4096) ? ceil_div(N, 32) : ceil_div(N, 16); }
 
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
     switch (epi) {

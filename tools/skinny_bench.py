@@ -41,7 +41,7 @@ def run(name, epi, N, K, ln, dbg, iters=400):
           f"{e0.elapsed_time(e1) / (iters // 50 * 50) * 1e3:7.2f} us/launch", flush=True)
 
 
-for dbg in (0, 8, 7):
-    d = dbg | (2 << 8) | (8 << 12)
-    run("qkv-like (ACT, LN) nw=8", 2, 1536, 512, True, d)
-    run("fc1 (ACT, LN) nw=8", 2, 2048, 512, True, d)
+for ln in (True, False):
+    for dbg in (0, 1, 2, 4, 7):
+        d = dbg | (2 << 8) | (8 << 12)
+        run("qkv-shape nw=8", 2, 1536, 512, ln, d)
