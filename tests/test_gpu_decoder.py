@@ -167,3 +167,43 @@ def test_decoder_L_shape_greedy_and_top_p_run():
     b2 = eng.generate(prompts, 64, temperature=1.0, top_k=None, top_p=0.9, seed=5).cpu()
     assert torch.equal(a, b2) and int(a.min()) >= 0 and int(a.max()) < 2000
     assert len(set(a[0].tolist())) > 8      # it really samples
+
+
+def test_full_size_batch64_ctx1024_properties():
+    """BASELINE configs[2] at full size (Decoder-S, B=64, 5-token prompts -> 1024 tokens).  The oracle takes
+    minutes here, so the checks are size-independent properties: run-to-run bit-identical ids (no atomics
+    anywhere), rows independent of batch composition (a row of the B=64 run equals the same prompt in a
+    B=8 run: different skinny-GEMM row tiles, same numbers), cache length = prompt + steps, ids in range;
+    the first 48 steps of 4 rows are additionally pinned by the reference's golden ids."""
+    from mgea.decoder import DecoderEngine
+    import numpy as np
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "decoder_S.npz"))
+    seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
+    sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=64, max_ctx=1024)
+    gold = [g[f"prompt{i}"].tolist() for i in range(4)]
+    prompts = gold + synth.integers(3, "fs", (60, 5), 0, vocab).tolist()
+    n = 1024 - 5
+    a = eng.generate(prompts, n, top_k=1).cpu()
+    b = eng.generate(prompts, n, top_k=1).cpu()
+    assert torch.equal(a, b)
+    assert int(a.min()) >= 0 and int(a.max()) < vocab
+    assert eng.context_lengths().cpu().tolist() == [1024] * 64
+    for i in range(4):
+        assert a[i, :48].tolist() == g[f"greedy{i}"][5:].tolist()
+    sub = [prompts[j] for j in (0, 5, 17, 33, 40, 41, 62, 63)]
+    c = eng.generate(sub, n, top_k=1).cpu()
+    for r, j in enumerate((0, 5, 17, 33, 40, 41, 62, 63)):
+        assert torch.equal(c[r], a[j]), f"row {j} depends on batch composition"
+
+
+def test_empty_and_oversize_inputs(golden):
+    g = golden("decoder_tiny")
+    eng, _, _ = make(g, max_batch=2)
+    with pytest.raises(ValueError):
+        eng.generate([[1, 2], []], 4, top_k=1)                      # empty prompt
+    with pytest.raises(ValueError):
+        eng.generate([[1, 2, 3]], eng.max_ctx, top_k=1)             # prompt + steps > reserved context
+    out = eng.generate([[1, 2, 3]], eng.max_ctx - 3, top_k=1)       # exactly the maximum
+    assert out.shape == (1, eng.max_ctx - 3)
+    assert eng.generate([[1, 2, 3]], 0, top_k=1).shape == (1, 0)    # zero steps: prefill only
