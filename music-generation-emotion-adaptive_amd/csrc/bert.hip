@@ -181,16 +181,25 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
                                   D, c.vocab, st));
     for (int l = 0; l < c.n_layers; ++l) {
-        MGEA_TRY(gemm(h->h, D, h->lw(l, BL_QKVW), M, 3 * D, D, &Sk));
-        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
-                                 3 * D, M, 3 * D, ACT_NONE, st));
+        if (M > 64) {   // bias (+ GELU below) inside the GEMM epilogue: no slab round trip
+            MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, h->lw(l, BL_QKVW), D, h->lw(l, BL_QKVB), h->qkv, 3 * D, M, 3 * D, D,
+                                              ACT_NONE, st));
+        } else {
+            MGEA_TRY(gemm(h->h, D, h->lw(l, BL_QKVW), M, 3 * D, D, &Sk));
+            MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
+                                     3 * D, M, 3 * D, ACT_NONE, st));
+        }
         MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, 0, st));
         MGEA_TRY(gemm(h->ctx, D, h->lw(l, BL_OUTW), M, D, D, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->h, nullptr,
                                     h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, M, D, 1, st));
-        MGEA_TRY(gemm(h->h, D, h->lw(l, BL_L1W), M, Hd, D, &Sk));
-        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, Hd), (int)slab_ld(Hd), h->lw(l, BL_L1B), h->ffn, Hd, M, Hd,
-                                 ACT_GELU, st));
+        if (M > 64) {
+            MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, h->lw(l, BL_L1W), D, h->lw(l, BL_L1B), h->ffn, Hd, M, Hd, D, ACT_GELU, st));
+        } else {
+            MGEA_TRY(gemm(h->h, D, h->lw(l, BL_L1W), M, Hd, D, &Sk));
+            MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, Hd), (int)slab_ld(Hd), h->lw(l, BL_L1B), h->ffn, Hd, M, Hd,
+                                     ACT_GELU, st));
+        }
         MGEA_TRY(gemm(h->ffn, Hd, h->lw(l, BL_L2W), M, D, Hd, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->h, nullptr,
                                     h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, M, D, 1, st));

@@ -52,6 +52,8 @@ __host__ __device__ static inline int64_t tiled_off(int row, int n) { return ((i
 // ldp = round_up(N, 64); slab stride = M * ldp floats.  K % 32 == 0.
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* P, int M, int N, int K,
                     int split_k, hipStream_t st);
+int launch_gemm_f32_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo,
+                             int M, int N, int K, int act, hipStream_t st);
 // chooses split_k so the grid fills the chip (deterministic function of the shape)
 int pick_split_k(int M, int N, int K);
 static inline int64_t slab_ld(int N) { return round_up(N, 64); }

@@ -79,6 +79,13 @@ struct mgea_decoder {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *slabs = nullptr,
           *logits = nullptr, *stats = nullptr, *pmax_val = nullptr;
     int32_t* pmax_idx = nullptr;
+    // decode lanes: generate() may split the batch into n_lanes row groups that run the step on
+    // forked graph branches (the skinny GEMMs of one lane overlap the HBM-bound attention of another)
+    struct LaneBufs { float *x = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *stats = nullptr, *pmax_val = nullptr;
+                      int32_t* pmax_idx = nullptr; hipStream_t stream = nullptr; hipEvent_t done_ev = nullptr; };
+    LaneBufs lanes[4];
+    hipEvent_t fork_ev = nullptr;
+    int n_lanes = 1, g_lanes = 0;
     bool no_graph = false;       // MGEA_DECODER_NOGRAPH=1: launch every step eagerly (rocprofv3 --pmc runs)
     bool force_unfused = false;  // MGEA_DECODER_UNFUSED=1: keep the 9-launch-per-layer path (A/B and fallback)
     int64_t slab_cap = 0;
@@ -242,9 +249,14 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
             PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_OUTB), h->x,
                                         h->xn, h->lw(l, L_LN2W), h->lw(l, L_LN2B), c.ln_eps, M, C, 0, st));
         }
-        MGEA_TRY(gemm(h, post ? h->x : h->xn, C, h->lw(l, L_FC1W), M, F, C, &S, st));
-        PROF(PC_ROWOP, launch_bias_act(h->slabs, S, slab_floats(M, F), (int)slab_ld(F), h->lw(l, L_FC1B), h->hbuf, F, M, F,
-                                 post ? ACT_RELU : ACT_GELU, st));
+        if (M > 64) {   // bias + activation inside the GEMM epilogue (no slab round trip)
+            PROF(PC_GEMM, launch_gemm_f32_bias_act(post ? h->x : h->xn, C, h->lw(l, L_FC1W), C, h->lw(l, L_FC1B), h->hbuf, F, M, F,
+                                                   C, post ? ACT_RELU : ACT_GELU, st));
+        } else {
+            MGEA_TRY(gemm(h, post ? h->x : h->xn, C, h->lw(l, L_FC1W), M, F, C, &S, st));
+            PROF(PC_ROWOP, launch_bias_act(h->slabs, S, slab_floats(M, F), (int)slab_ld(F), h->lw(l, L_FC1B), h->hbuf, F, M, F,
+                                     post ? ACT_RELU : ACT_GELU, st));
+        }
         MGEA_TRY(gemm(h, h->hbuf, F, h->lw(l, L_FC2W), M, C, F, &S, st));
         if (post) {
             PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_FC2B), h->x,
@@ -259,6 +271,26 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
     return MGEA_OK;
 }
 
+// Everything one fused decode pass touches besides the weights: the whole batch (main buffers) or one
+// lane (its own activation buffers, per-row state pointers offset to the lane's first row).
+struct Bufs {
+    float *x, *qkv, *att, *hbuf, *stats, *pmax_val;
+    int32_t *pmax_idx, *page_table, *ctx_len, *cur_ids, *done, *row_step, *sampled, *ids_hist;
+    float* logits;
+};
+
+Bufs main_bufs(mgea_decoder* h) {
+    return Bufs{h->x, h->qkv, h->att, h->hbuf, h->stats, h->pmax_val, h->pmax_idx, h->page_table, h->ctx_len, h->cur_ids,
+                h->done, h->row_step, h->sampled, h->ids_hist, h->logits};
+}
+
+Bufs lane_bufs(mgea_decoder* h, int j, int row0) {
+    const auto& L = h->lanes[j];
+    return Bufs{L.x, L.qkv, L.att, L.hbuf, L.stats, L.pmax_val, L.pmax_idx, h->page_table + (int64_t)row0 * h->max_pages,
+                h->ctx_len + row0, h->cur_ids + row0, h->done + row0, h->row_step + row0, h->sampled + row0,
+                h->ids_hist + (int64_t)row0 * h->ids_hist_stride, h->logits + (int64_t)row0 * h->cfg.vocab};
+}
+
 // Fused path for M = B*T <= 64 rows in the KV-cache block mode: 5 launches per layer
 // (gemm_skinny.hip); x carries per-row LayerNorm partial statistics between kernels.
 bool fused_ok(const mgea_decoder* h, int M) {
@@ -266,7 +298,7 @@ bool fused_ok(const mgea_decoder* h, int M) {
            !h->force_unfused;
 }
 
-int run_blocks_fused(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
+int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, M = B * T;
     int n_part = 1, part_cnt = C;  // the embedding kernel leaves one whole-row partial
@@ -274,91 +306,99 @@ int run_blocks_fused(mgea_decoder* h, int B, int T, const int32_t* lens, bool us
         SkinnyArgs a{};
         a.M = M; a.eps = c.ln_eps;
         // ln1 + in_proj + KV append
-        a.A = h->x; a.lda = C; a.W = h->lw(l, L_INW); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
-        a.lnw = h->lw(l, L_LN1W); a.lnb = h->lw(l, L_LN1B); a.stats_in = h->stats; a.n_part = n_part; a.part_cnt = part_cnt;
-        a.out = h->qkv; a.ldo = 3 * C;
-        a.pool = h->kv; a.layer = l; a.page_table = h->page_table; a.max_pages = h->max_pages; a.ctx_len = h->ctx_len;
+        a.A = u.x; a.lda = C; a.W = h->lw(l, L_INW); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
+        a.lnw = h->lw(l, L_LN1W); a.lnb = h->lw(l, L_LN1B); a.stats_in = u.stats; a.n_part = n_part; a.part_cnt = part_cnt;
+        a.out = u.qkv; a.ldo = 3 * C;
+        a.pool = h->kv; a.layer = l; a.page_table = u.page_table; a.max_pages = h->max_pages; a.ctx_len = u.ctx_len;
         a.lens = lens; a.T = T; a.C = C;
         PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
         if (use_cache_attn) {
-            PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T, C, 1, st));
+            PROF(PC_ATTN_PAGED, launch_attn_paged(u.qkv, h->kv, l, u.page_table, h->max_pages, u.ctx_len, lens, u.att, B, T, C, 1, st));
         } else {
-            PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, 1, st));
+            PROF(PC_ATTN_DENSE, launch_attn_dense(u.qkv, lens, nullptr, u.att, B, T, c.n_head, h->dh, 1, st));
         }
         // out_proj + residual (+ stats for ln2)
         SkinnyArgs o{};
         o.M = M; o.eps = c.ln_eps;
-        o.A = h->att; o.lda = C; o.W = h->lw(l, L_OUTW); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
-        o.out = h->x; o.ldo = C; o.stats_out = h->stats;
+        o.A = u.att; o.lda = C; o.W = h->lw(l, L_OUTW); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
+        o.out = u.x; o.ldo = C; o.stats_out = u.stats;
         PROF(PC_GEMM, launch_skinny(EPI_RES, o, st));
         n_part = C / 16; part_cnt = 16;
         // ln2 + mlp.0 + GELU
         SkinnyArgs f{};
         f.M = M; f.eps = c.ln_eps;
-        f.A = h->x; f.lda = C; f.W = h->lw(l, L_FC1W); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
-        f.lnw = h->lw(l, L_LN2W); f.lnb = h->lw(l, L_LN2B); f.stats_in = h->stats; f.n_part = n_part; f.part_cnt = part_cnt;
-        f.out = h->hbuf; f.ldo = F; f.act = ACT_GELU;
+        f.A = u.x; f.lda = C; f.W = h->lw(l, L_FC1W); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
+        f.lnw = h->lw(l, L_LN2W); f.lnb = h->lw(l, L_LN2B); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
+        f.out = u.hbuf; f.ldo = F; f.act = ACT_GELU;
         PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
         // mlp.2 + residual (+ stats for the next ln1)
         SkinnyArgs r{};
         r.M = M; r.eps = c.ln_eps;
-        r.A = h->hbuf; r.lda = F; r.W = h->lw(l, L_FC2W); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
-        r.out = h->x; r.ldo = C; r.stats_out = h->stats;
+        r.A = u.hbuf; r.lda = F; r.W = h->lw(l, L_FC2W); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
+        r.out = u.x; r.ldo = C; r.stats_out = u.stats;
         PROF(PC_GEMM, launch_skinny(EPI_RES, r, st));
     }
     return MGEA_OK;
 }
 
-StepState step_state(mgea_decoder* h, int eos) {
+StepState step_state(mgea_decoder* h, const Bufs& u, int eos) {
     StepState s;
-    s.cur_ids = h->cur_ids;
-    s.ctx_len = h->ctx_len;
-    s.done = h->done;
-    s.row_step = h->row_step;
+    s.cur_ids = u.cur_ids;
+    s.ctx_len = u.ctx_len;
+    s.done = u.done;
+    s.row_step = u.row_step;
     s.n_done = h->n_done;
-    s.ids_out = h->ids_hist;
+    s.ids_out = u.ids_hist;
     s.n_steps = h->ids_hist_stride;
     s.eos_id = eos;
     return s;
 }
 
-// one decode step on cur_ids (T = 1); logits_out optional
+// One fused decode step (T = 1) over the rows of `u` (the whole batch or one lane).
 // primed: x already holds the embedding (+ LN statistics) of cur_ids -- generate() keeps that invariant by
 // fusing the next step's embedding into this step's tail, so a replayed step is 32 launches.
+int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler_config& sc, float* logits_out,
+                       hipStream_t st, bool primed) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, V = c.vocab;
+    const bool greedy = sc.top_k == 1;
+    // [embed,] 6 x (qkv, attention, out-proj, fc1, fc2), head (+ per-tile argmax), finalize [+ next embed]
+    const int abs_pos = c.pos_mode == MGEA_POS_ABSOLUTE;
+    if (!primed)
+        PROF(PC_ROWOP, launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, 1, C, V,
+                                          c.seq_len, abs_pos, st));
+    MGEA_TRY(run_blocks_fused(h, u, B, 1, nullptr, true, st));
+    SkinnyArgs a{};
+    a.M = B; a.A = u.x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
+    a.out = logits_out ? logits_out : (greedy ? nullptr : u.logits);
+    a.ldo = V; a.pmax_val = u.pmax_val; a.pmax_idx = u.pmax_idx;
+    PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
+    if (greedy && primed) {
+        PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
+                                                    u.sampled, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, C, V, c.seq_len,
+                                                    abs_pos, st));
+    } else if (greedy) {
+        PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
+                                              u.sampled, B, st));
+    } else {
+        PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st));
+        PROF(PC_ROWOP, launch_advance(u.sampled, step_state(h, u, sc.eos_id), B, st));
+        if (primed)
+            PROF(PC_ROWOP, launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, 1, C, V,
+                                              c.seq_len, abs_pos, st));
+    }
+    return MGEA_OK;
+}
+
+// one decode step on cur_ids (T = 1) for the whole batch; logits_out optional
 int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* logits_out, hipStream_t st,
                  bool primed = false) {
     const auto& c = h->cfg;
     const int C = c.d_model, V = c.vocab;
     const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
     const bool greedy = sc.top_k == 1;
-    if (fused_ok(h, B)) {
-        // [embed,] 6 x (qkv, attention, out-proj, fc1, fc2), head (+ per-tile argmax), finalize [+ next embed]
-        const int abs_pos = c.pos_mode == MGEA_POS_ABSOLUTE;
-        if (!primed)
-            PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1,
-                                              C, V, c.seq_len, abs_pos, st));
-        MGEA_TRY(run_blocks_fused(h, B, 1, nullptr, true, st));
-        SkinnyArgs a{};
-        a.M = B; a.A = h->x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
-        a.out = logits_out ? logits_out : (greedy ? nullptr : h->logits);
-        a.ldo = V; a.pmax_val = h->pmax_val; a.pmax_idx = h->pmax_idx;
-        PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
-        if (greedy && primed) {
-            PROF(PC_SAMPLE, launch_argmax_advance_embed(h->pmax_val, h->pmax_idx, skinny_logits_tiles(B, V), step_state(h, sc.eos_id),
-                                                        h->sampled, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, C, V,
-                                                        c.seq_len, abs_pos, st));
-        } else if (greedy) {
-            PROF(PC_SAMPLE, launch_argmax_advance(h->pmax_val, h->pmax_idx, skinny_logits_tiles(B, V), step_state(h, sc.eos_id),
-                                                  h->sampled, B, st));
-        } else {
-            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
-            PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, sc.eos_id), B, st));
-            if (primed)
-                PROF(PC_ROWOP, launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B,
-                                                  1, C, V, c.seq_len, abs_pos, st));
-        }
-        return MGEA_OK;
-    }
+    if (fused_ok(h, B)) return enqueue_step_fused(h, main_bufs(h), B, sc, logits_out, st, primed);
+    const Bufs u = main_bufs(h);
     PROF(PC_ROWOP, launch_embed_ln(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                              post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, 1, C,
                              V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
@@ -369,7 +409,58 @@ int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* l
     PROF(PC_SAMPLE, launch_logits_argmax(h->slabs, S, slab_floats(B, V), (int)slab_ld(V), h->head_b(), lg, B, V,
                                   greedy ? h->sampled : nullptr, st));
     if (!greedy) PROF(PC_SAMPLE, launch_sample(lg, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
-    PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, sc.eos_id), B, st));
+    PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, u, sc.eos_id), B, st));
+    return MGEA_OK;
+}
+
+// The decode step of generate(): one fused pass over the whole batch, or -- with n_lanes > 1 -- one pass
+// per lane (contiguous row group), each on its own stream between a fork and a join event, so that
+// under graph capture the lanes become parallel branches.
+struct LaneSplit { int n; int row0[4]; int rows[4]; };
+LaneSplit split_lanes(const mgea_decoder* h, int B) {
+    LaneSplit sp{};
+    int n = h->n_lanes;
+    while (n > 1 && B / n < 8) n >>= 1;          // keep at least 8 rows per lane
+    sp.n = n;
+    for (int j = 0; j < n; ++j) {
+        sp.row0[j] = (int)((int64_t)B * j / n);
+        sp.rows[j] = (int)((int64_t)B * (j + 1) / n) - sp.row0[j];
+    }
+    return sp;
+}
+
+int enqueue_gen_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_t st) {
+    if (!fused_ok(h, B)) return enqueue_step(h, B, sc, nullptr, st, false);
+    const LaneSplit sp = split_lanes(h, B);
+    if (sp.n == 1) return enqueue_step_fused(h, main_bufs(h), B, sc, nullptr, st, true);
+    if (h->prof_now) {   // event-timed eager step: lanes one after another on the launch stream
+        for (int j = 0; j < sp.n; ++j)
+            MGEA_TRY(enqueue_step_fused(h, lane_bufs(h, j, sp.row0[j]), sp.rows[j], sc, nullptr, st, true));
+        return MGEA_OK;
+    }
+    MGEA_CHECK_HIP(hipEventRecord(h->fork_ev, st));
+    for (int j = 0; j < sp.n; ++j) {
+        hipStream_t ls = j == 0 ? st : h->lanes[j].stream;
+        if (j > 0) MGEA_CHECK_HIP(hipStreamWaitEvent(ls, h->fork_ev, 0));
+        MGEA_TRY(enqueue_step_fused(h, lane_bufs(h, j, sp.row0[j]), sp.rows[j], sc, nullptr, ls, true));
+        if (j > 0) {
+            MGEA_CHECK_HIP(hipEventRecord(h->lanes[j].done_ev, ls));
+            MGEA_CHECK_HIP(hipStreamWaitEvent(st, h->lanes[j].done_ev, 0));
+        }
+    }
+    return MGEA_OK;
+}
+
+// embedding (+ LN statistics) of cur_ids into the buffers the next generate() step will read
+int prime_gen(mgea_decoder* h, int B, hipStream_t st) {
+    if (!fused_ok(h, B)) return MGEA_OK;
+    const auto& c = h->cfg;
+    const LaneSplit sp = split_lanes(h, B);
+    for (int j = 0; j < sp.n; ++j) {
+        const Bufs u = sp.n == 1 ? main_bufs(h) : lane_bufs(h, j, sp.row0[j]);
+        MGEA_TRY(launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, sp.n == 1 ? B : sp.rows[j],
+                                    1, c.d_model, c.vocab, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+    }
     return MGEA_OK;
 }
 
@@ -425,7 +516,7 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     if (fused_ok(h, (int)M)) {
         MGEA_TRY(launch_embed_stats(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, T, C, V,
                                     c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
-        MGEA_TRY(run_blocks_fused(h, B, T, lens, cache_attn, st));
+        MGEA_TRY(run_blocks_fused(h, main_bufs(h), B, T, lens, cache_attn, st));
     } else {
         MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                                  post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
@@ -490,6 +581,9 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
         h->force_unfused = e && e[0] == '1';
         const char* g = getenv("MGEA_DECODER_NOGRAPH");
         h->no_graph = g && g[0] == '1';
+        const char* ln = getenv("MGEA_DECODER_LANES");
+        h->n_lanes = ln ? atoi(ln) : 1;
+        if (h->n_lanes != 2 && h->n_lanes != 4) h->n_lanes = 1;
     }
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
@@ -526,6 +620,21 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
         mgea_decoder_destroy(h);
         return rc;
     }
+    if (h->n_lanes > 1) {   // per-lane 64-row activation buffers (k-tiled), streams and join events
+        const int64_t C = cfg->d_model, F = cfg->d_ff, tiles = ceil_div(cfg->vocab, 16);
+        bool ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+        for (int j = 0; j < h->n_lanes && ok; ++j) {
+            auto& L = h->lanes[j];
+            ok = hipMalloc((void**)&L.x, 64 * C * 4) == hipSuccess && hipMalloc((void**)&L.qkv, 64 * 3 * C * 4) == hipSuccess &&
+                 hipMalloc((void**)&L.att, 64 * C * 4) == hipSuccess && hipMalloc((void**)&L.hbuf, 64 * F * 4) == hipSuccess &&
+                 hipMalloc((void**)&L.stats, 64 * (C / 16 + 1) * 2 * 4) == hipSuccess &&
+                 hipMalloc((void**)&L.pmax_val, 64 * tiles * 4) == hipSuccess &&
+                 hipMalloc((void**)&L.pmax_idx, 64 * tiles * 4) == hipSuccess &&
+                 hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) return fail(MGEA_ENOMEM, "lane buffer allocation failed");
+    }
     *out = h;
     return MGEA_OK;
 }
@@ -538,6 +647,14 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist};
     for (void* q : p)
         if (q) (void)hipFree(q);
+    for (auto& L : h->lanes) {
+        void* lp[] = {L.x, L.qkv, L.att, L.hbuf, L.stats, L.pmax_val, L.pmax_idx};
+        for (void* q : lp)
+            if (q) (void)hipFree(q);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.done_ev) (void)hipEventDestroy(L.done_ev);
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     delete h;
     return MGEA_OK;
 }
@@ -590,10 +707,10 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
     if (n_steps == 0) return MGEA_OK;
 
     // capture one decode step (all per-step state lives in device memory, so one graph serves every step)
-    if (!h->no_graph && (!h->gexec || h->g_batch != B || !same_sampler(h->g_samp, *s))) {
+    if (!h->no_graph && (!h->gexec || h->g_batch != B || h->g_lanes != h->n_lanes || !same_sampler(h->g_samp, *s))) {
         drop_graph(h);
         MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B));
+        const int rc = enqueue_gen_step(h, B, *s, st);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(st, &g);
         if (rc != MGEA_OK) {
@@ -604,24 +721,23 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
         h->graph = g;
         MGEA_CHECK_HIP(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
         h->g_batch = B;
+        h->g_lanes = h->n_lanes;
         h->g_samp = *s;
         size_t nn = 0;
         (void)hipGraphGetNodes(g, nullptr, &nn);
         h->counters[0] = (int64_t)nn;
     }
-    if (fused_ok(h, B))   // prime x with the embedding of the re-fed last prompt token (api_cache.py:167)
-        MGEA_TRY(launch_embed_stats(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, 1, c.d_model,
-                                    c.vocab, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+    MGEA_TRY(prime_gen(h, B, st));   // x <- embedding of the re-fed last prompt token (api_cache.py:167)
     int launched = 0;
     int32_t host_done = 0;
     for (int i = 0; i < n_steps; ++i) {
         if (h->prof_stride > 0 && (i % h->prof_stride) == h->prof_stride / 2) {
             h->prof_now = true;  // this step runs eagerly with HIP events around every launch
-            const int rc = enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B));
+            const int rc = enqueue_gen_step(h, B, *s, st);
             h->prof_now = false;
             MGEA_TRY(rc);
         } else if (h->no_graph) {
-            MGEA_TRY(enqueue_step(h, B, *s, nullptr, st, fused_ok(h, B)));
+            MGEA_TRY(enqueue_gen_step(h, B, *s, st));
         } else {
             MGEA_CHECK_HIP(hipGraphLaunch(h->gexec, st));
         }

@@ -25,7 +25,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, int lda,
                                                          const float* __restrict__ W, int ldw,
                                                          float* __restrict__ P, int M, int N, int K, int ldp,
-                                                         int kt_per_split, int tiles_n) {
+                                                         int kt_per_split, int tiles_n, const float* __restrict__ bias,
+                                                         int act) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int A_F4 = BM * 8 / 256, W_F4 = BN * 8 / 256;
@@ -128,8 +129,16 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = n0 + wn * WN + n * 16 + 4 * g;
-                if (col < ldp)  // ldp = round_up(N, 64): whole 16-B groups are in or out
-                    st4(Pz + (int64_t)row * ldp + col, make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]));
+                if (col < ldp) {  // ldp = round_up(N, 64) for slabs: whole 16-B groups are in or out
+                    float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+                    if (bias) {   // direct epilogue (no split-K): P is the final [M, ldp] output, N % 4 == 0
+                        if (col >= N) continue;
+                        v = add4(v, ld4(bias + col));
+                        if (act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                        if (act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    }
+                    st4(Pz + (int64_t)row * ldp + col, v);
+                }
             }
         }
     }
@@ -143,6 +152,19 @@ int pick_split_k(int M, int N, int K) {
     int s = 1;
     while (tiles * s < 384 && s * 2 <= KT && s < 32) s *= 2;
     return s;
+}
+
+// Large-M GEMM with the bias / activation epilogue inside the kernel: out[M, ldo] = act(A W^T + bias).
+// Saves the slab write + read of the two-kernel form (one HBM round trip of M x N floats).
+int launch_gemm_f32_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo,
+                             int M, int N, int K, int act, hipStream_t st) {
+    MGEA_REQUIRE(M > 64 && N % 4 == 0 && ldo % 4 == 0 && ldo >= N && K % 32 == 0 && bias, MGEA_EINVAL,
+                 "gemm_bias_act: bad shape M=%d N=%d K=%d ldo=%d", M, N, K, ldo);
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
+    hipLaunchKernelGGL((gemm_f32_nt_kernel<128, 128, 2, 2>), dim3(tm * tn, 1, 1), dim3(256), 0, st, A, lda, W, ldw, out, M, N, K,
+                       ldo, K / 32, tn, bias, act);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
 }
 
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* P, int M, int N, int K,
@@ -159,12 +181,12 @@ int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* P, 
         const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
         dim3 grid(tm * tn, 1, split_k);
         hipLaunchKernelGGL((gemm_f32_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, A, lda, W, ldw, P, M, N, K,
-                           ldp, kt_per, tn);
+                           ldp, kt_per, tn, (const float*)nullptr, 0);
     } else {
         const int tn = ceil_div(N, 64);
         dim3 grid(tn, 1, split_k);
         hipLaunchKernelGGL((gemm_f32_nt_kernel<64, 64, 1, 4>), grid, dim3(256), 0, st, A, lda, W, ldw, P, M, N, K,
-                           ldp, kt_per, tn);
+                           ldp, kt_per, tn, (const float*)nullptr, 0);
     }
     MGEA_CHECK_HIP(hipGetLastError());
     return split_k;  // > 0: number of slabs written
