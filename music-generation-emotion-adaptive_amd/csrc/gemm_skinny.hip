@@ -33,6 +33,10 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
     float* s_mean = red + (blockDim.x >> 6) * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
 
+    // grid.x is padded to a multiple of 8 so that the workgroups sharing a W tile (same blockIdx.x, different
+    // blockIdx.y) are a multiple of 8 apart in dispatch order = same XCD / same L2 (speed only)
+    const int n_tiles = (a.N + COLS - 1) / COLS;
+    if ((int)blockIdx.x >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -254,8 +258,8 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
             if (q == 0 && row_ok && a.pmax_val) {
-                a.pmax_val[(int64_t)row * gridDim.x + blockIdx.x] = best;
-                a.pmax_idx[(int64_t)row * gridDim.x + blockIdx.x] = bi;
+                a.pmax_val[(int64_t)row * n_tiles + blockIdx.x] = best;
+                a.pmax_idx[(int64_t)row * n_tiles + blockIdx.x] = bi;
             }
         }
     }
@@ -284,7 +288,7 @@ static int pick_waves(int K, bool ln, int mt) {
 template <int EPI, int MT, int NT = 1>
 static int launch_skinny_mt(const SkinnyArgs& a, int nw, hipStream_t st) {
     const bool ln = a.lnw != nullptr;
-    dim3 grid(ceil_div(a.N, 16 * NT), ceil_div(a.M, 16 * MT)), block(64 * nw);
+    dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
     const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
     if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
     else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
