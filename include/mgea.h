@@ -93,6 +93,9 @@ int mgea_decoder_arena_layout(const mgea_decoder_config* cfg, int64_t* offsets_f
 
 int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, mgea_decoder** out);
 int mgea_decoder_destroy(mgea_decoder* h);
+/* create() derives a decode-layout copy of the projection matrices from the arena.  If the caller
+ * rewrites the arena afterwards (new checkpoint into the same tensor), call this before the next step. */
+int mgea_decoder_refresh_weights(mgea_decoder* h, void* stream);
 
 /* Forget all cached tokens and reserve KV pages for `batch` rows of up to `max_len` tokens. */
 int mgea_decoder_reset(mgea_decoder* h, int32_t batch, int32_t max_len, void* stream);
@@ -193,10 +196,19 @@ int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* o
                            int32_t n_head, int32_t head_dim, void* stream);
 int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int32_t M,
                            int32_t C, float eps, void* stream);
+/* Layouts of the fused decode path.  The skinny GEMM reads both operands in MFMA-fragment order so that
+ * every wave load is 1 KB of consecutive bytes (see csrc/common.h):
+ *   tile_weights: W [N,K] row-major -> out_dev [mgea_op_tiled_weight_floats(N,K)] (rows padded to 32);
+ *   tile_rows:    [M<=64, N] row-major <-> the k-tiled activation buffer (64 * N floats), to_tiled != 0
+ *                 converts row-major -> tiled.  K % 32 == 0, N % 32 == 0. */
+int64_t mgea_op_tiled_weight_floats(int32_t N, int32_t K);
+int mgea_op_tile_weights(const float* w_dev, int32_t N, int32_t K, float* out_dev, void* stream);
+int mgea_op_tile_rows(const float* src_dev, float* dst_dev, int32_t M, int32_t N, int32_t to_tiled, void* stream);
 /* Fused skinny GEMM (decode step, M <= 64): out = epilogue(LN?(A) @ W^T + bias); epi 1 = residual
- * add into out + LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU).  LN prologue
- * when lnw_dev != NULL (stats_in_dev [M][n_part][2] partial (mean, M2) over part_cnt columns).
- * dbg = 0 (ablation bits for tools/skinny_bench.py). */
+ * add into out + LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU).  a_dev and out_dev are
+ * k-tiled activation buffers, w_dev is a tiled weight (above).  LN prologue when lnw_dev != NULL
+ * (stats_in_dev [M][n_part][2] partial (mean, M2) over part_cnt columns; n_part even, K in 256..1024).
+ * dbg = 0 (tools/skinny_bench.py, tools/skinny_phases.py). */
 int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev,
                    const float* lnw_dev, const float* lnb_dev, const float* stats_in_dev, int32_t n_part,
                    int32_t part_cnt, float* out_dev, float* stats_out_dev, int32_t M, int32_t N, int32_t K,

@@ -89,6 +89,16 @@ int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b
 
 /* ablation / micro-benchmark hook for the fused skinny GEMM (tools/skinny_bench.py): EPI_ACT or
  * EPI_RES on caller buffers; dbg bits skip A loads (1), W loads (2), MFMAs (4). */
+int64_t mgea_op_tiled_weight_floats(int32_t N, int32_t K) { return wtile_floats(N, K); }
+
+int mgea_op_tile_weights(const float* w_dev, int32_t N, int32_t K, float* out_dev, void* stream) {
+    return launch_tile_weights(w_dev, N, K, out_dev, (hipStream_t)stream);
+}
+
+int mgea_op_tile_rows(const float* src_dev, float* dst_dev, int32_t M, int32_t N, int32_t to_tiled, void* stream) {
+    return launch_tile_rows(src_dev, dst_dev, M, N, to_tiled, (hipStream_t)stream);
+}
+
 int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev, const float* lnw_dev,
                    const float* lnb_dev, const float* stats_in_dev, int32_t n_part, int32_t part_cnt, float* out_dev,
                    float* stats_out_dev, int32_t M, int32_t N, int32_t K, int32_t act, int32_t dbg, void* stream) {

@@ -40,11 +40,23 @@ const char* get_error();
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// "k-tiled" activation layout of the fused decode path: [k/32][64 rows][32]; element (row, n) of a
-// [<=64, N] matrix.  One 32-wide k-chunk of all 64 rows is 8 KB contiguous, so the A fragments of the
-// skinny GEMM (16 rows x 128 B per wave instruction pair) are whole, adjacent cache lines instead
-// of 16 lines that are a full row pitch (2-8 KB) apart.
-__host__ __device__ static inline int64_t tiled_off(int row, int n) { return ((int64_t)(n >> 5) * 64 + row) * 32 + (n & 31); }
+// "k-tiled" activation layout of the fused decode path, in MFMA-fragment order: a [<=64, N] matrix is cut
+// into 32-wide k-chunks of 2048 floats; inside a chunk the 16-byte group holding (row, k..k+3) sits at
+//   [row / 16][h = (k / 4) % 2][lane = (k / 8) % 4 * 16 + row % 16]
+// which is exactly the order in which the 64 lanes of a wave consume it in the skinny GEMM (lane = 16 g + c
+// feeds row c with k = k0 + 8 g + 4 h + s): one operand load instruction reads 1 KB of CONSECUTIVE bytes.
+// Measured on MI355X: a wave load whose lanes each fetch 16 B from a different 128-B line is served at about
+// one lane per clock (~16 B/clk, 36 GB/s per CU); consecutive lanes reach the 64 B/clk of the L1.
+__host__ __device__ static inline int64_t tiled_off(int row, int n) {
+    return (int64_t)(n >> 5) * 2048 + ((((row >> 4) * 2 + ((n >> 2) & 1)) * 64 + ((n >> 3) & 3) * 16 + (row & 15)) << 2) + (n & 3);
+}
+// The same idea for the weights of the skinny GEMMs (W [N, K] row-major in the arena): per (16-row tile,
+// 32-wide k-chunk) one 2 KB block [h][lane = 16 g + c][4] holding W[tile * 16 + c][chunk * 32 + 8 g + 4 h + s];
+// rows are padded to a multiple of 32 with zeros.  Built once per engine from the arena (launch_tile_weights).
+static inline int64_t wtile_floats(int N, int K) { return round_up(N, 32) * (int64_t)K; }
+int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st);
+// row-major [M, N] <-> k-tiled (to_tiled != 0: src row-major, dst tiled), for tests and tools
+int launch_tile_rows(const float* src, float* dst, int M, int N, int to_tiled, hipStream_t st);
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
 
@@ -149,7 +161,7 @@ enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
 
 struct SkinnyArgs {
     const float* A; int lda;
-    const float* W;            // [N, K]
+    const float* W;            // [N, K] in the tiled weight layout (launch_tile_weights)
     const float* bias;         // [N] or NULL
     int M, N, K;
     // LN prologue (lnw != NULL): per-row partial stats [64][n_part][2], each over `part_cnt` elements
@@ -165,6 +177,7 @@ struct SkinnyArgs {
     // LOGITS
     float* pmax_val; int32_t* pmax_idx;   // [64][n_tiles]
     int dbg;                   // ablation bits for tools/skinny_bench.py (0 in production)
+    int nw;                    // waves per workgroup (set by the launcher)
 };
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
 int skinny_logits_tiles(int M, int N);

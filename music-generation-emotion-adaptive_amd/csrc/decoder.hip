@@ -105,6 +105,12 @@ struct mgea_decoder {
     const float* lw(int layer, int j) const { return arena + off[2 + layer * L_COUNT + j]; }
     const float* head_w() const { return arena + off[2 + cfg.n_layer * L_COUNT]; }
     const float* head_b() const { return arena + off[3 + cfg.n_layer * L_COUNT]; }
+    // fragment-ordered copies of the five matrix kinds for the fused decode path (common.h: launch_tile_weights);
+    // index 4 * layer + {0 in_proj, 1 out_proj, 2 fc1, 3 fc2}, then the head
+    float* wt = nullptr;
+    std::vector<int64_t> wt_off;
+    const float* tw(int layer, int j) const { return wt + wt_off[4 * layer + j]; }
+    const float* head_tw() const { return wt + wt_off[4 * cfg.n_layer]; }
 };
 
 namespace {
@@ -293,20 +299,22 @@ Bufs lane_bufs(mgea_decoder* h, int j, int row0) {
 
 // Fused path for M = B*T <= 64 rows in the KV-cache block mode: 5 launches per layer
 // (gemm_skinny.hip); x carries per-row LayerNorm partial statistics between kernels.
+bool fused_geometry(const mgea_decoder_config& c) {
+    return c.block_mode == MGEA_BLOCK_PRELN_GELU && (c.d_model % 128) == 0 && c.d_model >= 256 && c.d_model <= 1024;
+}
 bool fused_ok(const mgea_decoder* h, int M) {
-    return h->cfg.block_mode == MGEA_BLOCK_PRELN_GELU && M <= 64 && (h->cfg.d_model % 128) == 0 && h->cfg.d_model <= 1024 &&
-           !h->force_unfused;
+    return fused_geometry(h->cfg) && M <= 64 && !h->force_unfused && h->wt;
 }
 
 int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, M = B * T;
-    int n_part = 1, part_cnt = C;  // the embedding kernel leaves one whole-row partial
+    int n_part = 2, part_cnt = C / 2;  // the embedding kernel leaves the whole-row statistics as two equal halves
     for (int l = 0; l < c.n_layer; ++l) {
         SkinnyArgs a{};
         a.M = M; a.eps = c.ln_eps;
         // ln1 + in_proj + KV append
-        a.A = u.x; a.lda = C; a.W = h->lw(l, L_INW); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
+        a.A = u.x; a.lda = C; a.W = h->tw(l, 0); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
         a.lnw = h->lw(l, L_LN1W); a.lnb = h->lw(l, L_LN1B); a.stats_in = u.stats; a.n_part = n_part; a.part_cnt = part_cnt;
         a.out = u.qkv; a.ldo = 3 * C;
         a.pool = h->kv; a.layer = l; a.page_table = u.page_table; a.max_pages = h->max_pages; a.ctx_len = u.ctx_len;
@@ -320,21 +328,21 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         // out_proj + residual (+ stats for ln2)
         SkinnyArgs o{};
         o.M = M; o.eps = c.ln_eps;
-        o.A = u.att; o.lda = C; o.W = h->lw(l, L_OUTW); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
+        o.A = u.att; o.lda = C; o.W = h->tw(l, 1); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
         o.out = u.x; o.ldo = C; o.stats_out = u.stats;
         PROF(PC_GEMM, launch_skinny(EPI_RES, o, st));
         n_part = C / 16; part_cnt = 16;
         // ln2 + mlp.0 + GELU
         SkinnyArgs f{};
         f.M = M; f.eps = c.ln_eps;
-        f.A = u.x; f.lda = C; f.W = h->lw(l, L_FC1W); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
+        f.A = u.x; f.lda = C; f.W = h->tw(l, 2); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
         f.lnw = h->lw(l, L_LN2W); f.lnb = h->lw(l, L_LN2B); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
         f.out = u.hbuf; f.ldo = F; f.act = ACT_GELU;
         PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
         // mlp.2 + residual (+ stats for the next ln1)
         SkinnyArgs r{};
         r.M = M; r.eps = c.ln_eps;
-        r.A = u.hbuf; r.lda = F; r.W = h->lw(l, L_FC2W); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
+        r.A = u.hbuf; r.lda = F; r.W = h->tw(l, 3); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
         r.out = u.x; r.ldo = C; r.stats_out = u.stats;
         PROF(PC_GEMM, launch_skinny(EPI_RES, r, st));
     }
@@ -369,7 +377,7 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
                                           c.seq_len, abs_pos, st));
     MGEA_TRY(run_blocks_fused(h, u, B, 1, nullptr, true, st));
     SkinnyArgs a{};
-    a.M = B; a.A = u.x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
+    a.M = B; a.A = u.x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
     a.out = logits_out ? logits_out : (greedy ? nullptr : u.logits);
     a.ldo = V; a.pmax_val = u.pmax_val; a.pmax_idx = u.pmax_idx;
     PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
@@ -525,7 +533,7 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     }
     if (logits_out && fused_ok(h, (int)M)) {
         SkinnyArgs a{};  // x is k-tiled on the fused path: the head is the skinny LOGITS kernel
-        a.M = (int)M; a.A = h->x; a.lda = C; a.W = h->head_w(); a.bias = h->head_b(); a.N = V; a.K = C;
+        a.M = (int)M; a.A = h->x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
         a.out = logits_out; a.ldo = V;
         MGEA_TRY(launch_skinny(EPI_LOGITS, a, st));
     } else if (logits_out) {
@@ -559,6 +567,37 @@ int mgea_decoder_arena_layout(const mgea_decoder_config* cfg, int64_t* offsets_f
         for (int i = 0; i < n; ++i) offsets_floats[i] = offs[i];
     if (n_tensors) *n_tensors = n;
     if (total_floats) *total_floats = total;
+    return MGEA_OK;
+}
+
+// (Re)derive the fragment-ordered matrices of the fused decode path from the arena; synchronous.
+static int build_tiled_weights(mgea_decoder* h, hipStream_t st) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, F = c.d_ff, V = c.vocab;
+    if (!h->wt) {
+        int64_t total = 0;
+        h->wt_off.clear();
+        for (int l = 0; l < c.n_layer; ++l) {
+            h->wt_off.push_back(total); total += wtile_floats(3 * C, C);
+            h->wt_off.push_back(total); total += wtile_floats(C, C);
+            h->wt_off.push_back(total); total += wtile_floats(F, C);
+            h->wt_off.push_back(total); total += wtile_floats(C, F);
+        }
+        h->wt_off.push_back(total); total += wtile_floats(V, C);
+        if (hipMalloc((void**)&h->wt, (size_t)total * sizeof(float)) != hipSuccess) {
+            h->wt = nullptr;
+            set_error("decoder_create: allocation of the decode-layout weights (%lld MB) failed", (long long)(total * 4 >> 20));
+            return MGEA_ENOMEM;
+        }
+    }
+    for (int l = 0; l < c.n_layer; ++l) {
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_INW), 3 * C, C, h->wt + h->wt_off[4 * l + 0], st));
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_OUTW), C, C, h->wt + h->wt_off[4 * l + 1], st));
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_FC1W), F, C, h->wt + h->wt_off[4 * l + 2], st));
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_FC2W), C, F, h->wt + h->wt_off[4 * l + 3], st));
+    }
+    MGEA_TRY(launch_tile_weights(h->head_w(), V, C, h->wt + h->wt_off[4 * c.n_layer], st));
+    MGEA_CHECK_HIP(hipStreamSynchronize(st));
     return MGEA_OK;
 }
 
@@ -635,8 +674,22 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
         }
         if (!ok) return fail(MGEA_ENOMEM, "lane buffer allocation failed");
     }
+    if (fused_geometry(*cfg)) {
+        const int rc2 = build_tiled_weights(h, nullptr);
+        if (rc2 != MGEA_OK) {
+            mgea_decoder_destroy(h);
+            return rc2;
+        }
+    }
     *out = h;
     return MGEA_OK;
+}
+
+int mgea_decoder_refresh_weights(mgea_decoder* h, void* stream) {
+    MGEA_REQUIRE(h, MGEA_EINVAL, "decoder handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!fused_geometry(h->cfg)) return MGEA_OK;
+    return build_tiled_weights(h, (hipStream_t)stream);
 }
 
 int mgea_decoder_destroy(mgea_decoder* h) {
@@ -644,7 +697,7 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     (void)hipDeviceSynchronize();
     drop_graph(h);
     free_ws(h);
-    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist};
+    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt};
     for (void* q : p)
         if (q) (void)hipFree(q);
     for (auto& L : h->lanes) {

@@ -13,8 +13,10 @@
 // through its L2 port (~45-70 GB/s per CU) stay at 64-256 KB.  Workgroups that share a W tile differ
 // by a multiple of gridDim.x (a multiple of 8) in dispatch order -> same XCD, so W is fetched from
 // HBM once and re-read from that XCD's L2 (speed only; results never depend on placement).
-//   * operands go HBM/L2 -> registers directly (32 contiguous bytes per lane); activations use the
-//     k-tiled layout of common.h (tiled_off) so an A fragment load is 16 adjacent 128-B lines;
+//   * operands go HBM/L2 -> registers directly, and BOTH are stored in MFMA-fragment order (common.h:
+//     tiled_off for activations, launch_tile_weights for the matrices), so every operand load instruction
+//     of a wave is 1 KB of consecutive bytes: the row-major version, 16 B per lane from 16 different lines,
+//     ran at a quarter of the L1 rate and was what bounded these kernels (tools/skinny_phases.py);
 //   * v_mfma_f32_16x16x4_f32 (exact fp32), issued "swapped" so a lane owns 4 consecutive output
 //     columns; the k order inside the chain is a fixed permutation (k = k0 + 8g + 4h + s) applied
 //     to both operands; results are run-to-run bit-identical;
@@ -25,40 +27,92 @@
 
 namespace mgea {
 
+// Sum over each aligned group of 16 lanes with DPP butterflies (xor 1, xor 2, then mirrors of 8 and 16 lanes, which
+// equal xor 4 / xor 8 once the smaller groups are uniform): every lane gets the bit-identical total, and the
+// four steps cost a few cycles each instead of four LDS-crossbar round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 // NT = 16-column tiles per workgroup (2 only for the LM head: 64 rows x 32 columns halves the A bytes per output)
 template <int EPI, bool LN, int MT, int NT>
-__global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(SkinnyArgs a) {
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ 2*ROWS floats of LN stats)
-    float* s_mean = red + (blockDim.x >> 6) * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
+    // k-chunks (32 wide) a wave keeps in flight.  Measured (tools/skinny_phases.py): deeper (4, 8) does not
+    // help -- a CU's vector memory path sustains only ~40-60 GB/s of L2 hits however many loads are queued
+    constexpr int DEPTH = 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ LN: 2*ROWS stats, 2*K gamma/beta)
+    const int NW = a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
+    float* s_mean = red + NW * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
+    float* s_gam = s_rstd + ROWS;
+    float* s_bet = s_gam + a.K;
 
     // grid.x is padded to a multiple of 8 so that the workgroups sharing a W tile (same blockIdx.x, different
     // blockIdx.y) are a multiple of 8 apart in dispatch order = same XCD / same L2 (speed only)
+    // The kernel-argument block (4 x 64-B lines) is read with scalar loads the compiler otherwise sinks to
+    // their first use, block by block: each is a cold scalar-cache miss of several hundred ns on the critical
+    // path of a ~6 us kernel.  Asking for every field here makes them ONE batch of loads and one wait.
+    asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.lnw), "s"(a.lnb), "s"(a.eps),
+                       "s"(a.stats_in), "s"(a.n_part), "s"(a.part_cnt), "s"(a.out), "s"(a.ldo), "s"(a.stats_out), "s"(a.act), "s"(a.dbg), "s"(a.nw));
+    if (EPI == EPI_QKV)
+        asm volatile("" :: "s"(a.pool.base), "s"(a.pool.H), "s"(a.pool.dh), "s"(a.pool.layer_stride), "s"(a.layer), "s"(a.page_table),
+                           "s"(a.max_pages), "s"(a.ctx_len), "s"(a.lens), "s"(a.T), "s"(a.C));
+    if (EPI == EPI_LOGITS) asm volatile("" :: "s"(a.pmax_val), "s"(a.pmax_idx));
     const int n_tiles = (a.N + COLS - 1) / COLS;
     if ((int)blockIdx.x >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = blockDim.x >> 6;
+    // tools/skinny_phases.py phase timing (dbg bit 20): 100 MHz timestamps of workgroup phases, written behind
+    // the statistics in stats_out; the extra waits it inserts are only there in that mode
+    long long* ts = (a.dbg & (1 << 20)) ? reinterpret_cast<long long*>(a.stats_out + 64 * (a.N >> 4) * 2) +
+                                              (blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define MGEA_TS(i) do { if (ts && tid == 0) ts[i] = wall_clock64(); } while (0)
+    MGEA_TS(0);
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * COLS;
     const int m0 = blockIdx.y * ROWS;
     const int kw = a.K / NW, kbeg = wave * kw;
     const int nchunk = kw >> 5;
 
-    // k-tiled A: rows >= M of the 64-row buffer hold stale data whose products are never stored
-    const float* arow[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) arow[mt] = a.A + tiled_off(m0 + mt * 16 + c, kbeg + 8 * g);
-    const float* wrow[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        int wr = n0 + nt * 16 + c;
-        wr = wr < a.N ? wr : a.N - 1;
-        wrow[nt] = a.W + (int64_t)wr * a.K + kbeg + 8 * g;
+    // LN prologue, part 1.  A CU's vector-memory path returns loads in issue order across ALL its waves
+    // (measured: a separate statistics wave gains nothing), so the small LayerNorm loads must be the FIRST
+    // ones every wave issues: one float4 (two (mean, M2) partials of the producer's 16-column tiles) per
+    // lane, 16 lanes per row, and gamma/beta once per workgroup (they go to LDS; per-lane global loads of
+    // gamma/beta cost as many vector-memory cycles as A itself).  Everything from here to the K loop is
+    // branch-free on purpose: the compiler then waits with an exact vmcnt for these loads only and the
+    // merge runs under the flight of the operand loads.
+    float4 st0, st1, gam4, bet4;
+    int s_lr = 0, s_j = 0;
+    bool s_ok = false;
+    if (LN) {
+        const int slot = tid < ROWS * 16 ? tid : 0;
+        s_lr = slot >> 4; s_j = slot & 15;
+        s_ok = m0 + s_lr < a.M;
+        const float* sp = a.stats_in + ((int64_t)(s_ok ? m0 + s_lr : 0) * a.n_part) * 2;
+        const int p0 = 2 * s_j, p1 = 32 + 2 * s_j;   // n_part <= 64 and even (host check)
+        st0 = ld4(sp + 2 * (p0 < a.n_part ? p0 : 0));
+        // (no default values for the conditional loads: a select after them would wait for them right here)
+        if (a.n_part > 32) st1 = ld4(sp + 2 * (p1 < a.n_part ? p1 : 0));
+        if (4 * tid < a.K) {   // K = 512: waves 0 and 1 only
+            gam4 = ld4(a.lnw + 4 * tid);
+            bet4 = ld4(a.lnb + 4 * tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep these four loads ahead of the operand loads
     }
-    const float* gptr = a.lnw + kbeg + 8 * g;
-    const float* bptr = a.lnb + kbeg + 8 * g;
+    // operands in fragment order (common.h): lane l of a wave reads bytes [16 l, 16 l + 16) of a 1 KB block.
+    // A: rows >= M of the 64-row buffer hold stale data whose products are never stored
+    const float* atile[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) atile[mt] = a.A + tiled_off(m0 + mt * 16, kbeg) + lane * 4;
+    const float* wtile[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        wtile[nt] = a.W + ((int64_t)((n0 >> 4) + nt) * (a.K >> 5) + (kbeg >> 5)) * 512 + lane * 4;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -66,38 +120,33 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wf[2][NT][2] = {}, af[2][MT][2] = {}, gf[2][2] = {}, bf[2][2] = {};
+    float4 wf[DEPTH][NT][2], af[DEPTH][MT][2];
     auto load_chunk = [&](int buf, int ch) {
         const int ko = ch * 32;
-        if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                wf[buf][nt][0] = ld4(wrow[nt] + ko);
-                wf[buf][nt][1] = ld4(wrow[nt] + ko + 4);
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            wf[buf][nt][0] = ld4(wtile[nt] + ch * 512);
+            wf[buf][nt][1] = ld4(wtile[nt] + ch * 512 + 256);
         }
-        if (!(a.dbg & 1)) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                af[buf][mt][0] = ld4(arow[mt] + (int64_t)ch * 64 * 32);
-                af[buf][mt][1] = ld4(arow[mt] + (int64_t)ch * 64 * 32 + 4);
-            }
-        }
-        if (LN && !(a.dbg & 8)) {
-            gf[buf][0] = ld4(gptr + ko); gf[buf][1] = ld4(gptr + ko + 4);
-            bf[buf][0] = ld4(bptr + ko); bf[buf][1] = ld4(bptr + ko + 4);
+        for (int mt = 0; mt < MT; ++mt) {
+            af[buf][mt][0] = ld4(atile[mt] + ch * 2048);
+            af[buf][mt][1] = ld4(atile[mt] + ch * 2048 + 256);
         }
     };
     float mu[MT], rs[MT];
-    auto compute_chunk = [&](int buf) {
-        if (a.dbg & 4) return;
+    auto compute_chunk = [&](int buf, int ch) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            float4 gg, bb;
+            if (LN) {
+                gg = *reinterpret_cast<const float4*>(&s_gam[kbeg + ch * 32 + 8 * g + 4 * h]);
+                bb = *reinterpret_cast<const float4*>(&s_bet[kbeg + ch * 32 + 8 * g + 4 * h]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float4 x = af[buf][mt][h];
                 if (LN) {
-                    const float4 gg = gf[buf][h], bb = bf[buf][h];
                     x.x = (x.x - mu[mt]) * rs[mt] * gg.x + bb.x;
                     x.y = (x.y - mu[mt]) * rs[mt] * gg.y + bb.y;
                     x.z = (x.z - mu[mt]) * rs[mt] * gg.z + bb.z;
@@ -114,59 +163,51 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
             }
         }
     };
-    // every wave puts its first two k-chunks in flight before anything else (the kernel is
-    // latency-bound), then the LN statistics are merged under that flight
-    load_chunk(0, 0);
-    if (nchunk > 1) load_chunk(1, 1);
+    // every wave puts its first DEPTH k-chunks in flight (LN: a wave owns >= DEPTH chunks, host check)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (LN || d < nchunk) load_chunk(d, d);
     if (LN) {
-        // merge the producer's per-tile (mean, M2) partials: thread t -> row t>>2, partials q, q+4, ...
-        if (tid < ROWS * 4) {
-            const int lr = tid >> 2, q = tid & 3, row = m0 + lr;
-            // every partial covers the same number of columns (part_cnt), so
-            //   mean = average of the tile means,  M2 = sum M2_t + part_cnt * sum (mean_t - mean)^2
-            const bool ok = row < a.M;
-            const float* sp = a.stats_in + ((int64_t)(ok ? row : 0) * a.n_part) * 2;
-            // all (<= 16 per thread, n_part <= 64) partials are requested at once: a rolled loop would
-            // serialise one L2 round trip per partial (measured +3 us per LN kernel)
-            float2 part[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int p = q + 4 * i;
-                part[i] = p < a.n_part ? *reinterpret_cast<const float2*>(sp + 2 * p) : make_float2(0.f, 0.f);
-            }
-            float sm = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sm += part[i].x;
-            sm += __shfl_xor(sm, 1, 64);
-            sm += __shfl_xor(sm, 2, 64);
-            const float mean = sm * (1.0f / (float)a.n_part);
-            const float cnt = (float)a.part_cnt;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float d = part[i].x - mean;
-                m2 += (q + 4 * i < a.n_part) ? part[i].y + cnt * d * d : 0.f;
-            }
-            m2 += __shfl_xor(m2, 1, 64);
-            m2 += __shfl_xor(m2, 2, 64);
-            if (q == 0) {
-                s_mean[lr] = ok ? mean : 0.f;
-                s_rstd[lr] = ok ? 1.0f / sqrtf(m2 / (cnt * (float)a.n_part) + a.eps) : 0.f;
-            }
+        __builtin_amdgcn_sched_barrier(0);   // ... and the merge (which waits for them) behind the operand loads' issue
+        // every partial covers the same number of columns (part_cnt), so
+        //   mean = average of the tile means,  M2 = sum M2_t + part_cnt * sum (mean_t - mean)^2
+        const bool v0 = 2 * s_j < a.n_part, v1 = 32 + 2 * s_j < a.n_part;
+        float sm = (v0 ? st0.x + st0.z : 0.f) + (v1 ? st1.x + st1.z : 0.f);
+        sm = row16_sum(sm);
+        const float mean = sm * (1.0f / (float)a.n_part);
+        MGEA_TS(6);
+        const float cnt = (float)a.part_cnt;
+        const float d0 = st0.x - mean, d1 = st0.z - mean, d2 = st1.x - mean, d3 = st1.z - mean;
+        float m2 = (v0 ? (st0.y + cnt * d0 * d0) + (st0.w + cnt * d1 * d1) : 0.f) +
+                   (v1 ? (st1.y + cnt * d2 * d2) + (st1.w + cnt * d3 * d3) : 0.f);
+        m2 = row16_sum(m2);
+        if (tid < ROWS * 16 && s_j == 0) {
+            s_mean[s_lr] = s_ok ? mean : 0.f;
+            s_rstd[s_lr] = s_ok ? 1.0f / sqrtf(m2 / (cnt * (float)a.n_part) + a.eps) : 0.f;
         }
+        if (4 * tid < a.K) {
+            *reinterpret_cast<float4*>(&s_gam[4 * tid]) = gam4;
+            *reinterpret_cast<float4*>(&s_bet[4 * tid]) = bet4;
+        }
+        MGEA_TS(7);
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + c]; rs[mt] = s_rstd[mt * 16 + c]; }
     }
-    for (int ch = 0; ch < nchunk; ch += 2) {
-        compute_chunk(0);
-        if (ch + 2 < nchunk) load_chunk(0, ch + 2);
-        if (ch + 1 < nchunk) {
-            compute_chunk(1);
-            if (ch + 3 < nchunk) load_chunk(1, ch + 3);
+    MGEA_TS(1);
+    if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    MGEA_TS(2);
+    for (int ch = 0; ch < nchunk; ch += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (ch + d < nchunk) {
+                compute_chunk(d, ch + d);
+                if (ch + d + DEPTH < nchunk) load_chunk(d, ch + d + DEPTH);
+            }
         }
     }
 
+    MGEA_TS(3);
     // partial tile of this wave -> LDS: D[i = column 4g + r][j = row c]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -175,9 +216,10 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
             *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * COLS + nt * 16 + 4 * g]) =
                 make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
     __syncthreads();
+    MGEA_TS(4);
 
     // epilogue: thread t -> local row t / (4*NT), columns n0 + 4*(t % (4*NT)) .. +3
-    for (int t = tid; t < ROWS * 4 * NT; t += blockDim.x) {
+    for (int t = tid; t < ROWS * 4 * NT; t += NW * 64) {
         const int lr = t / (4 * NT), q = t % (4 * NT), row = m0 + lr;
         const int n = n0 + 4 * q;
         // the NW partial tiles are read at once (a rolled loop serialises one LDS round trip per wave)
@@ -263,6 +305,9 @@ __global__ __launch_bounds__((MT == 4) ? 512 : 1024) void gemm_skinny_kernel(Ski
             }
         }
     }
+    if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    MGEA_TS(5);
+#undef MGEA_TS
 }
 
 // rows per workgroup: enough workgroups to cover the chip, as few re-reads of W as possible
@@ -281,15 +326,17 @@ static int pick_waves(int K, bool ln, int mt) {
     // 4 threads per row of the tile.
     const int cap = 8;  // 16 waves per workgroup measured equal or slower on every decode shape
     for (int nw = cap; nw >= 1; --nw)
-        if ((K / 32) % nw == 0) return nw;
+        if ((K / 32) % nw == 0 && (!ln || K / 32 / nw >= 2)) return nw;   // LN: two k-chunks per wave, unconditionally in flight
     return 1;
 }
 
 template <int EPI, int MT, int NT = 1>
-static int launch_skinny_mt(const SkinnyArgs& a, int nw, hipStream_t st) {
-    const bool ln = a.lnw != nullptr;
+static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
+    const bool ln = a_in.lnw != nullptr;
+    SkinnyArgs a = a_in;
+    a.nw = nw;
     dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
-    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
+    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT + 2 * a.K : 0)) * sizeof(float);
     if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
     else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
     MGEA_CHECK_HIP(hipGetLastError());
@@ -307,12 +354,15 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
         const int nw_head = pick_waves(a.K, false, 2);
         return launch_skinny_mt<EPI_LOGITS, 2, 2>(a, nw_head, st);
     }
-    const int mt = ((a.dbg >> 8) & 15) ? ((a.dbg >> 8) & 15) : pick_mt(a.M, a.N);
+    int mt = ((a.dbg >> 8) & 15) ? ((a.dbg >> 8) & 15) : pick_mt(a.M, a.N);
     int nw = pick_waves(a.K, ln, mt);
     if ((a.dbg >> 12) & 31) nw = (a.dbg >> 12) & 31;  // tools/skinny_bench.py override
+    while (ln && mt > 1 && nw * 64 < 16 * mt * 16) mt /= 2;   // the LN merge wants 16 lanes per tile row
     MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= 8, MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
     MGEA_REQUIRE(!ln || a.n_part <= 64, MGEA_EINVAL, "skinny gemm: more than 64 LayerNorm partials per row (%d)", a.n_part);
-    MGEA_REQUIRE(!ln || nw * 64 >= 16 * mt * 4, MGEA_EINVAL, "skinny gemm: LN prologue needs K %% 128 == 0 (K=%d)", a.K);
+    MGEA_REQUIRE(!ln || a.n_part % 2 == 0, MGEA_EINVAL, "skinny gemm: odd number of LayerNorm partials per row (%d)", a.n_part);
+    MGEA_REQUIRE(!ln || (nw * 64 >= 16 * mt * 16 && a.K <= 4 * 64 * nw && a.K / 32 / nw >= 2), MGEA_EINVAL,
+                 "skinny gemm: LN prologue needs 16 lanes per tile row, K/4 lanes for gamma/beta and two k-chunks per wave (K=%d, %d-row tiles, %d waves)", a.K, 16 * mt, nw);
     switch (mt) {
         case 1: return launch_skinny_mt<EPI, 1>(a, nw, st);
         case 2: return launch_skinny_mt<EPI, 2>(a, nw, st);
@@ -337,7 +387,48 @@ int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// x[m] = tok_emb[ids[m]] + pos_emb[pos] (k-tiled); stats[m] = (mean, M2) of the row (one partial)
+// W [N, K] row-major -> fragment-ordered tiles (common.h); one thread per float4 of the output
+__global__ __launch_bounds__(256) void tile_weights_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ out,
+                                                           int64_t n_f4) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_f4) return;
+    const int64_t blk = o >> 7;            // (tile, chunk) block of 128 float4
+    const int in = (int)(o & 127), h = in >> 6, lane = in & 63, g = lane >> 4, c = lane & 15;
+    const int chunks = K >> 5;
+    const int64_t tile = blk / chunks;
+    const int kc = (int)(blk % chunks);
+    const int64_t n = tile * 16 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = ld4(W + n * K + kc * 32 + 8 * g + 4 * h);
+    st4(out + o * 4, v);
+}
+
+int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st) {
+    MGEA_REQUIRE(W && out && N >= 1 && K >= 32 && K % 32 == 0, MGEA_EINVAL, "tile_weights: N=%d K=%d (K must be a multiple of 32)", N, K);
+    const int64_t n_f4 = wtile_floats(N, K) / 4;
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_f4 + 255) / 256)), dim3(256), 0, st, W, N, K, out, n_f4);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int N, int to_tiled) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into the row-major matrix
+    if (i >= (int64_t)M * (N >> 2)) return;
+    const int row = (int)(i / (N >> 2)), n = (int)(i % (N >> 2)) * 4;
+    if (to_tiled) st4(dst + tiled_off(row, n), ld4(src + (int64_t)row * N + n));
+    else          st4(dst + (int64_t)row * N + n, ld4(src + tiled_off(row, n)));
+}
+
+int launch_tile_rows(const float* src, float* dst, int M, int N, int to_tiled, hipStream_t st) {
+    MGEA_REQUIRE(src && dst && M >= 1 && M <= 64 && N >= 32 && N % 32 == 0, MGEA_EINVAL, "tile_rows: M=%d (1..64) N=%d (multiple of 32)", M, N);
+    const int64_t n = (int64_t)M * (N >> 2);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, M, N, to_tiled);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// x[m] = tok_emb[ids[m]] + pos_emb[pos] (k-tiled); stats[m] = (mean, M2) of the row, as two half-row partials
 __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
                                                          const int32_t* __restrict__ ctx_len,
                                                          const float* __restrict__ tok_emb,
@@ -383,7 +474,8 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restr
         }
     }
     const float m2 = bsum(q);
-    if (threadIdx.x == 0) *reinterpret_cast<float2*>(stats + m * 2) = make_float2(mean, m2);
+    // two equal half-row partials (the consumer merges pairs): (mean, M2/2) x 2 merges back to exactly (mean, M2)
+    if (threadIdx.x == 0) st4(stats + m * 4, make_float4(mean, 0.5f * m2, mean, 0.5f * m2));
 }
 
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
@@ -522,7 +614,7 @@ __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* 
         }
     }
     const float m2 = bsum(q);
-    if (tid == 0) *reinterpret_cast<float2*>(stats + (int64_t)b * 2) = make_float2(mean, m2);
+    if (tid == 0) st4(stats + (int64_t)b * 4, make_float4(mean, 0.5f * m2, mean, 0.5f * m2));   // as embed_stats_kernel
 }
 
 int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,

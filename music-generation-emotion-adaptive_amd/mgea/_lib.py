@@ -50,6 +50,7 @@ PROTOTYPES = {
     "mgea_decoder_arena_layout": (C.c_int, [C.POINTER(DecoderConfig), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
     "mgea_decoder_create": (C.c_int, [C.POINTER(DecoderConfig), _P, C.POINTER(_P)]),
     "mgea_decoder_destroy": (C.c_int, [_P]),
+    "mgea_decoder_refresh_weights": (C.c_int, [_P, _P]),
     "mgea_decoder_reset": (C.c_int, [_P, _I32, _I32, _P]),
     "mgea_decoder_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "mgea_decoder_step": (C.c_int, [_P, _P, C.POINTER(SamplerConfig), _P, _P, _P]),
@@ -71,6 +72,9 @@ PROTOTYPES = {
     "mgea_op_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_attention_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
+    "mgea_op_tiled_weight_floats": (C.c_int64, [_I32, _I32]),
+    "mgea_op_tile_weights": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "mgea_op_tile_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "mgea_op_skinny": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_sample": (C.c_int, [_P, _I32, _I32, C.POINTER(SamplerConfig), _I64, _P, _P, _P]),
 }

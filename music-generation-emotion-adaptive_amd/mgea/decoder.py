@@ -137,6 +137,11 @@ class DecoderEngine:
         return arena
 
     # ------------------------------------------------------------------ lifetime
+    def refresh_weights(self):
+        """Call after rewriting `self.arena` in place: the engine keeps a decode-layout copy of the matrices."""
+        with self._on_stream():
+            check(self.lib.mgea_decoder_refresh_weights(self.h, self._sp()))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mgea_decoder_destroy(self.h)

@@ -101,3 +101,57 @@ def sample(logits: torch.Tensor, temperature=1.0, top_k=50, top_p=None, seed=0, 
     probs = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_probs else None
     check(lib.mgea_op_sample(ptr(logits), B, V, C.byref(s), int(step), ptr(ids), ptr(probs), stream_ptr()))
     return (ids, probs) if want_probs else ids
+
+
+def tile_weights(w: torch.Tensor) -> torch.Tensor:
+    """W [N,K] row-major -> the fragment-ordered layout the skinny GEMM reads (rows padded to 32)."""
+    lib = _lib.load()
+    w = _dev(w.float())
+    N, K = w.shape
+    out = torch.empty(lib.mgea_op_tiled_weight_floats(N, K), dtype=torch.float32, device=w.device)
+    check(lib.mgea_op_tile_weights(ptr(w), N, K, ptr(out), stream_ptr()))
+    return out
+
+
+def tile_rows(x: torch.Tensor) -> torch.Tensor:
+    """[M<=64, N] row-major -> k-tiled activation buffer (64 * N floats; rows >= M are zero)."""
+    lib = _lib.load()
+    x = _dev(x.float())
+    M, N = x.shape
+    out = torch.zeros(64 * N, dtype=torch.float32, device=x.device)
+    check(lib.mgea_op_tile_rows(ptr(x), ptr(out), M, N, 1, stream_ptr()))
+    return out
+
+
+def untile_rows(t: torch.Tensor, M: int, N: int) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty(M, N, dtype=torch.float32, device=t.device)
+    check(lib.mgea_op_tile_rows(ptr(_dev(t)), ptr(out), M, N, 0, stream_ptr()))
+    return out
+
+
+def skinny(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
+           act: int = 0, ln: Optional[tuple] = None, dbg: int = 0):
+    """The fused decode-step GEMM on row-major inputs (tiling done here): epilogue `residual` (returns
+    (residual + a @ w^T + bias, per-16-column (mean, M2) statistics)) or activation `act` (0 none, 1 GELU,
+    2 ReLU).  ln = (gamma, beta, stats [M, K/16, 2]) applies LayerNorm to `a` from 16-column partial statistics."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    at, wt = tile_rows(a), tile_weights(w)
+    b = _dev(bias.float())
+    g = be = st = None
+    n_part = 0
+    if ln is not None:
+        g, be, st = _dev(ln[0].float()), _dev(ln[1].float()), _dev(ln[2].float())
+        n_part = st.shape[1]
+    stats_out = torch.zeros(64 * (N // 16) * 2 + 4096, dtype=torch.float32, device=a.device)
+    if residual is not None:
+        out = tile_rows(residual)
+        check(lib.mgea_op_skinny(1, ptr(at), ptr(wt), ptr(b), ptr(g), ptr(be), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
+                                 M, N, K, 0, dbg, stream_ptr()))
+        return untile_rows(out, M, N), stats_out[:M * (N // 16) * 2].view(M, N // 16, 2)
+    out = torch.zeros(64 * N, dtype=torch.float32, device=a.device)
+    check(lib.mgea_op_skinny(2, ptr(at), ptr(wt), ptr(b), ptr(g), ptr(be), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
+                             M, N, K, act, dbg, stream_ptr()))
+    return untile_rows(out, M, N)

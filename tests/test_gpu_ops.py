@@ -109,3 +109,52 @@ def test_sampler_distribution(ops):
     b = ops.sample(logits.cuda(), 1.0, None, None, seed=1, step=0)
     c = ops.sample(logits.cuda(), 1.0, None, None, seed=2, step=0)
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def tile_stats(x):
+    """(mean, M2) of every 16-column tile of x [M, K] -> [M, K/16, 2] (what a residual epilogue leaves)."""
+    t = x.double().reshape(x.shape[0], -1, 16)
+    mean = t.mean(-1)
+    return torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1).float()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 512), (37, 2048, 512), (1, 512, 256), (64, 2304, 768), (16, 3072, 768), (64, 4096, 1024)])
+def test_skinny_gemm_ln_gelu(ops, M, N, K):
+    """LayerNorm prologue (from 16-column partial statistics) + GEMM + bias + erf-GELU vs fp64, through the
+    fragment-ordered layouts (api_cache.py:60-62 and :73)."""
+    x = rnd(M, K, seed=1) + 0.3
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    b, g, be = rnd(N, seed=3), 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5)
+    dev = lambda t: t.cuda()
+    got = ops.skinny(dev(x), dev(w), dev(b), act=1, ln=(dev(g), dev(be), dev(tile_stats(x)))).cpu()
+    xd = x.double()
+    xn = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g.double() + be.double()
+    ref = torch.nn.functional.gelu(xn @ w.double().T + b.double())
+    assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 512, 512), (5, 512, 2048), (64, 768, 3072), (33, 1024, 1024), (64, 256, 4096)])
+def test_skinny_gemm_residual_stats(ops, M, N, K):
+    """GEMM + bias + residual in place, and the per-tile (mean, M2) statistics the next LayerNorm merges."""
+    a = rnd(M, K, seed=6)
+    w = rnd(N, K, seed=7, scale=K ** -0.5)
+    b, res = rnd(N, seed=8), rnd(M, N, seed=9)
+    got, stats = ops.skinny(a.cuda(), w.cuda(), b.cuda(), residual=res.cuda())
+    ref = res.double() + a.double() @ w.double().T + b.double()
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (stats.cpu() - tile_stats(ref.float())).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_weight_and_row_tiling_round_trip(ops):
+    x = rnd(37, 768, seed=10).cuda()
+    assert torch.equal(ops.untile_rows(ops.tile_rows(x), 37, 768), x)
+    w = rnd(100, 64, seed=11).cuda()   # 100 rows -> padded to 128
+    t = ops.tile_weights(w).cpu()
+    assert t.numel() == 128 * 64
+    # block (tile 1, chunk 1), h = 1, lane = 16 * 2 + 3  <->  W[16 + 3][32 + 8 * 2 + 4 .. + 3]
+    blk = t.view(8, 2, 2, 64, 4)
+    assert torch.equal(blk[1, 1, 1, 35], w.cpu()[19, 52:56])
+    assert torch.equal(blk[6, 0, 0, 5], torch.zeros(4))   # row 101 is padding

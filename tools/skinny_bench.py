@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Micro-benchmark / ablation of the fused skinny GEMM on the decode-step shapes (runs on the GPU box).
 Times back-to-back launches from a captured hipGraph-free loop; the ~8 us floor is host launch cost,
-so read DIFFERENCES between variants, not absolutes.  dbg bits: 1 skip A loads, 2 skip W loads,
-4 skip MFMAs; dbg >> 8 forces the row-tile count MT."""
+so read DIFFERENCES between variants, not absolutes.  (dbg >> 8) & 15 forces the row-tile count MT,
+(dbg >> 12) & 31 the waves per workgroup; tools/skinny_phases.py gives the in-kernel phase timing."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "music-generation-emotion-adaptive_amd"))
 import torch
-from mgea import _lib
+from mgea import _lib, ops
 from mgea._lib import ptr, check, stream_ptr
 
 lib = _lib.load()
@@ -16,7 +16,7 @@ dev = "cuda:0"
 
 def run(name, epi, N, K, ln, dbg, iters=400):
     M = 64
-    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5
+    a = torch.randn(M, K, device=dev); w = ops.tile_weights(torch.randn(N, K, device=dev) * K ** -0.5)
     bias = torch.randn(N, device=dev); lnw = torch.ones(K, device=dev); lnb = torch.zeros(K, device=dev)
     stats = torch.zeros(M, 32, 2, device=dev); stats[:, :, 1] = 16.0
     out = torch.zeros(M, N, device=dev); so = torch.zeros(M, N // 16, 2, device=dev)
@@ -41,7 +41,9 @@ def run(name, epi, N, K, ln, dbg, iters=400):
           f"{e0.elapsed_time(e1) / (iters // 50 * 50) * 1e3:7.2f} us/launch", flush=True)
 
 
-for ln in (True, False):
-    for dbg in (0, 1, 2, 4, 7):
-        d = dbg | (2 << 8) | (8 << 12)
-        run("qkv-shape nw=8", 2, 1536, 512, ln, d)
+# sweep of row tiles (mt) and waves (nw) on the decode-step shapes
+for name, epi, N, K, ln in (("qkv", 2, 1536, 512, True), ("fc1", 2, 2048, 512, True), ("out-proj", 1, 512, 512, False),
+                            ("fc2", 1, 512, 2048, False)):
+    for mt in (1, 2):
+        for nw in (4, 8):
+            run(f"{name} mt={mt} nw={nw}", epi, N, K, ln, (mt << 8) | (nw << 12))
