@@ -106,7 +106,13 @@ int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const fl
     a.A = a_dev; a.lda = K; a.W = w_dev; a.bias = bias_dev; a.M = M; a.N = N; a.K = K;
     a.lnw = lnw_dev; a.lnb = lnb_dev; a.eps = 1e-5f; a.stats_in = stats_in_dev; a.n_part = n_part; a.part_cnt = part_cnt;
     a.out = out_dev; a.ldo = N; a.stats_out = stats_out_dev; a.act = act; a.dbg = dbg;
-    MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
+    MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES || epi == EPI_LOGITS, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
+    if (epi == EPI_LOGITS) {   // LM head: logits [M,N] row-major in out_dev (or NULL); per-tile (max, argmax) partials in stats_out_dev
+        MGEA_REQUIRE(stats_out_dev, MGEA_EINVAL, "op_skinny: the LOGITS epilogue writes its partials to stats_out_dev");
+        const int tiles = skinny_logits_tiles(M, N);
+        a.pmax_val = stats_out_dev;
+        a.pmax_idx = reinterpret_cast<int32_t*>(stats_out_dev + (int64_t)64 * tiles);
+    }
     return launch_skinny(epi, a, (hipStream_t)stream);
 }
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
     // k-chunks (32 wide) a wave keeps in flight.  Measured (tools/skinny_phases.py): deeper (4, 8) does not
     // help -- a CU's vector memory path sustains only ~40-60 GB/s of L2 hits however many loads are queued
-    constexpr int DEPTH = 2;
+    constexpr int DEPTH = (!LN && MT * NT == 1) ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ LN: 2*ROWS stats, 2*K gamma/beta)
     const int NW = a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
     float* s_mean = red + NW * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
@@ -167,6 +167,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (LN || d < nchunk) load_chunk(d, d);
+    // QKV epilogue, first hop of its page lookup (branch-free, behind the operand loads): where the row's
+    // new token goes.  The second hop and the other epilogue operands are requested after the K loop.
+    const int e_lr = tid / (4 * NT), e_q = tid % (4 * NT);   // this thread's first epilogue item
+    const int e_row = m0 + e_lr, e_n = n0 + 4 * e_q;
+    int e_ctx = 0, e_len = 0;
+    if (EPI == EPI_QKV) {
+        const int pb = e_row < a.M ? e_row / a.T : 0;
+        e_ctx = a.ctx_len[pb];
+        e_len = (a.lens ? a.lens : a.ctx_len)[pb];
+    }
     if (LN) {
         __builtin_amdgcn_sched_barrier(0);   // ... and the merge (which waits for them) behind the operand loads' issue
         // every partial covers the same number of columns (part_cnt), so
@@ -208,6 +218,18 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     }
 
     MGEA_TS(3);
+    // the epilogue's own global operands are requested now, so that their round trip runs under the MFMA
+    // drain, the LDS reduction and the barrier instead of after them
+    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_x = e_bias;
+    int e_phys = 0;
+    if (tid < ROWS * 4 * NT) {
+        if (EPI != EPI_LOGITS && a.bias) e_bias = ld4(a.bias + e_n);
+        if (EPI == EPI_RES && e_row < a.M) e_x = ld4(a.out + tiled_off(e_row, e_n));
+        if (EPI == EPI_QKV && e_row < a.M && e_n >= a.C) {
+            const int page = (e_ctx + e_row % a.T) >> 6;
+            if (page < a.max_pages) e_phys = a.page_table[(e_row / a.T) * a.max_pages + page];
+        }
+    }
     // partial tile of this wave -> LDS: D[i = column 4g + r][j = row c]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -233,9 +255,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         for (int w = 1; w < 8; ++w)
             if (w < NW) v = add4(v, pv[w]);
         const bool row_ok = row < a.M;
+        const bool first = t == tid;   // the operands requested before the reduction belong to this pass
         if (EPI != EPI_LOGITS) {
             // N % 16 == 0 for these epilogues (checked on the host)
-            if (a.bias) v = add4(v, ld4(a.bias + n));
+            if (a.bias) v = add4(v, first ? e_bias : ld4(a.bias + n));
         }
         if (EPI == EPI_ACT) {
             if (a.act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         if (EPI == EPI_RES) {
             float* xp = a.out + tiled_off(row, n);           // residual stream x is k-tiled
             if (row_ok) {
-                v = add4(v, ld4(xp));
+                v = add4(v, first ? e_x : ld4(xp));
                 st4(xp, v);
             }
             // (mean, M2) of this row over the tile's 16 columns, for the next LayerNorm
@@ -262,14 +285,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         }
         if (EPI == EPI_QKV) {
             const int b = row_ok ? row / a.T : 0, tt = row_ok ? row % a.T : 0;
-            const bool real = row_ok && (a.lens ? (tt < a.lens[b]) : true);
+            const bool real = row_ok && (a.lens ? (tt < (first ? e_len : a.lens[b])) : true);
             if (!real) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row_ok) st4(a.out + (int64_t)row * a.ldo + n, v);
             if (real && n >= a.C) {
-                const int pos = a.ctx_len[b] + tt;
+                const int pos = (first ? e_ctx : a.ctx_len[b]) + tt;
                 const int page = pos >> 6, slot = pos & 63;
                 if (page < a.max_pages) {
-                    const int phys = a.page_table[b * a.max_pages + page];
+                    const int phys = first ? e_phys : a.page_table[b * a.max_pages + page];
                     const int64_t pf = a.pool.page_floats();
                     const int isv = n >= 2 * a.C;
                     const int nn = n - (isv ? 2 * a.C : a.C);
@@ -349,7 +372,7 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
-    if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !(a.dbg >> 8)) {
+    if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !((a.dbg >> 8) & 0x1FF)) {
         // LM head: 64 rows x 32 columns per workgroup (one per CU at V = 8324), W fetched from HBM once
         const int nw_head = pick_waves(a.K, false, 2);
         return launch_skinny_mt<EPI_LOGITS, 2, 2>(a, nw_head, st);

@@ -41,9 +41,12 @@ def run(name, epi, N, K, ln, dbg, iters=400):
           f"{e0.elapsed_time(e1) / (iters // 50 * 50) * 1e3:7.2f} us/launch", flush=True)
 
 
-# sweep of row tiles (mt) and waves (nw) on the decode-step shapes
-for name, epi, N, K, ln in (("qkv", 2, 1536, 512, True), ("fc1", 2, 2048, 512, True), ("out-proj", 1, 512, 512, False),
-                            ("fc2", 1, 512, 2048, False)):
-    for mt in (1, 2):
-        for nw in (4, 8):
-            run(f"{name} mt={mt} nw={nw}", epi, N, K, ln, (mt << 8) | (nw << 12))
+SHAPES = (("qkv", 2, 1536, 512, True), ("fc1", 2, 2048, 512, True), ("out-proj", 1, 512, 512, False), ("fc2", 1, 512, 2048, False))
+if len(sys.argv) > 1 and sys.argv[1] == "default":   # the launcher's own choice only (e.g. under rocprofv3 --kernel-trace --stats)
+    for name, epi, N, K, ln in SHAPES:
+        run(name, epi, N, K, ln, 0)
+else:   # sweep of row tiles (mt) and waves (nw) on the decode-step shapes
+    for name, epi, N, K, ln in SHAPES:
+        for mt in (1, 2):
+            for nw in (4, 8):
+                run(f"{name} mt={mt} nw={nw}", epi, N, K, ln, (mt << 8) | (nw << 12))

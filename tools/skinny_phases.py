@@ -21,14 +21,14 @@ def run(name, epi, N, K, ln, mt=0, nw=0, abl=0):
     bias = torch.randn(N, device=dev); lnw = torch.ones(K, device=dev); lnb = torch.zeros(K, device=dev)
     stats = torch.zeros(M, 32, 2, device=dev); stats[:, :, 1] = 16.0
     out = torch.zeros(M, N, device=dev)
-    n_stat = M * (N // 16) * 2
+    n_stat = 64 * (N // 16) * 2
     max_wg = (N // 16 + 8) * 4
     so = torch.zeros(n_stat + max_wg * 16, device=dev)
     dbg = (mt << 8) | (nw << 12) | abl
 
     def go(d):
         check(lib.mgea_op_skinny(epi, ptr(a), ptr(w), ptr(bias), ptr(lnw) if ln else None, ptr(lnb) if ln else None,
-                                 ptr(stats), 32, 16, ptr(out), ptr(so), M, N, K, 1 if epi == 2 else 0, d, stream_ptr()))
+                                 ptr(stats), 32, 16, ptr(out) if epi != 3 else None, ptr(so), M, N, K, 1 if epi == 2 else 0, d, stream_ptr()))
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         for _ in range(5): go(dbg)
@@ -58,6 +58,7 @@ run("qkv-like", 2, 1536, 512, True)
 run("fc1", 2, 2048, 512, True)
 run("out-proj", 1, 512, 512, False)
 run("fc2", 1, 512, 2048, False)
+run("head", 3, 8324, 512, False)
 run("ln N1024", 2, 1024, 512, True, mt=2)
 run("ln N4096", 2, 4096, 512, True, mt=2)
 run("res N1024", 1, 1024, 512, False)
