@@ -204,13 +204,18 @@ int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b
 int64_t mgea_op_tiled_weight_floats(int32_t N, int32_t K);
 int mgea_op_tile_weights(const float* w_dev, int32_t N, int32_t K, float* out_dev, void* stream);
 int mgea_op_tile_rows(const float* src_dev, float* dst_dev, int32_t M, int32_t N, int32_t to_tiled, void* stream);
-/* Fused skinny GEMM (decode step, M <= 64): out = epilogue(LN?(A) @ W^T + bias); epi 1 = residual
- * add into out + LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU).  a_dev and out_dev are
- * k-tiled activation buffers, w_dev is a tiled weight (above).  LN prologue when lnw_dev != NULL
- * (stats_in_dev [M][n_part][2] partial (mean, M2) over part_cnt columns; n_part even, K in 256..1024).
- * dbg = 0 (tools/skinny_bench.py, tools/skinny_phases.py). */
+/* LayerNorm folded into the matrix it feeds: wt_out_dev = tiles of gamma[k] * W[n,k], c1[n] = the row sums of those
+ * products, c2[n] = sum_k beta[k] * W[n,k] + bias[n], so that LN(x) @ W^T + bias = rstd * (x @ W'^T - mean * c1) + c2. */
+int mgea_op_fold_ln(const float* w_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
+                    int32_t N, int32_t K, float* wt_out_dev, float* c1_out_dev, float* c2_out_dev, void* stream);
+/* Fused skinny GEMM (decode step, M <= 64): out = epilogue(A @ W^T + bias); epi 1 = residual add into out +
+ * LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU), 3 = LM head (logits [M,N] row-major in out_dev
+ * or NULL, per-tile (max, argmax) partials in stats_out_dev).  a_dev and out_dev are k-tiled activation buffers,
+ * w_dev is a tiled weight (above).  Folded LayerNorm of A when ln_c1_dev != NULL: w_dev / ln_c1_dev / bias_dev are
+ * mgea_op_fold_ln's wt / c1 / c2 and stats_in_dev [M][n_part][2] holds partial (mean, M2) over part_cnt columns
+ * each (n_part even, <= 64).  dbg = 0 (tools/skinny_bench.py, tools/skinny_phases.py). */
 int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev,
-                   const float* lnw_dev, const float* lnb_dev, const float* stats_in_dev, int32_t n_part,
+                   const float* ln_c1_dev, const float* stats_in_dev, int32_t n_part,
                    int32_t part_cnt, float* out_dev, float* stats_out_dev, int32_t M, int32_t N, int32_t K,
                    int32_t act, int32_t dbg, void* stream);
 /* Sampler on a logits matrix [B,V]; step selects the Philox counter.  probs_out_dev [B,V] or NULL

@@ -95,16 +95,21 @@ int mgea_op_tile_weights(const float* w_dev, int32_t N, int32_t K, float* out_de
     return launch_tile_weights(w_dev, N, K, out_dev, (hipStream_t)stream);
 }
 
+int mgea_op_fold_ln(const float* w_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, int32_t N, int32_t K,
+                    float* wt_out_dev, float* c1_out_dev, float* c2_out_dev, void* stream) {
+    return launch_ln_fold(w_dev, gamma_dev, beta_dev, bias_dev, N, K, wt_out_dev, c1_out_dev, c2_out_dev, (hipStream_t)stream);
+}
+
 int mgea_op_tile_rows(const float* src_dev, float* dst_dev, int32_t M, int32_t N, int32_t to_tiled, void* stream) {
     return launch_tile_rows(src_dev, dst_dev, M, N, to_tiled, (hipStream_t)stream);
 }
 
-int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev, const float* lnw_dev,
-                   const float* lnb_dev, const float* stats_in_dev, int32_t n_part, int32_t part_cnt, float* out_dev,
+int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const float* bias_dev, const float* ln_c1_dev,
+                   const float* stats_in_dev, int32_t n_part, int32_t part_cnt, float* out_dev,
                    float* stats_out_dev, int32_t M, int32_t N, int32_t K, int32_t act, int32_t dbg, void* stream) {
     SkinnyArgs a{};
     a.A = a_dev; a.lda = K; a.W = w_dev; a.bias = bias_dev; a.M = M; a.N = N; a.K = K;
-    a.lnw = lnw_dev; a.lnb = lnb_dev; a.eps = 1e-5f; a.stats_in = stats_in_dev; a.n_part = n_part; a.part_cnt = part_cnt;
+    a.ln_c1 = ln_c1_dev; a.eps = 1e-5f; a.stats_in = stats_in_dev; a.n_part = n_part; a.part_cnt = part_cnt;
     a.out = out_dev; a.ldo = N; a.stats_out = stats_out_dev; a.act = act; a.dbg = dbg;
     MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES || epi == EPI_LOGITS, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
     if (epi == EPI_LOGITS) {   // LM head: logits [M,N] row-major in out_dev (or NULL); per-tile (max, argmax) partials in stats_out_dev

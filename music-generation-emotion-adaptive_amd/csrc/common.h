@@ -54,7 +54,11 @@ __host__ __device__ static inline int64_t tiled_off(int row, int n) {
 // 32-wide k-chunk) one 2 KB block [h][lane = 16 g + c][4] holding W[tile * 16 + c][chunk * 32 + 8 g + 4 h + s];
 // rows are padded to a multiple of 32 with zeros.  Built once per engine from the arena (launch_tile_weights).
 static inline int64_t wtile_floats(int N, int K) { return round_up(N, 32) * (int64_t)K; }
-int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st);
+int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st, const float* gamma = nullptr);
+// LayerNorm folded into the matrix it feeds: out = tiles of gamma[k] * W[n,k]; c1[n] = sum_k of those products,
+// c2[n] = sum_k beta[k] * W[n,k] + bias[n] (sums in fp64, once per engine)
+int launch_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, float* out,
+                   float* c1, float* c2, hipStream_t st);
 // row-major [M, N] <-> k-tiled (to_tiled != 0: src row-major, dst tiled), for tests and tools
 int launch_tile_rows(const float* src, float* dst, int M, int N, int to_tiled, hipStream_t st);
 
@@ -164,8 +168,9 @@ struct SkinnyArgs {
     const float* W;            // [N, K] in the tiled weight layout (launch_tile_weights)
     const float* bias;         // [N] or NULL
     int M, N, K;
-    // LN prologue (lnw != NULL): per-row partial stats [64][n_part][2], each over `part_cnt` elements
-    const float* lnw; const float* lnb; float eps;
+    // folded LayerNorm (ln_c1 != NULL): W holds gamma * W, ln_c1 [N] = its row sums, bias = beta @ W^T + bias
+    // (launch_ln_fold); per-row partial stats [64][n_part][2], each over `part_cnt` elements
+    const float* ln_c1; float eps;
     const float* stats_in; int n_part; int part_cnt;
     // outputs
     float* out; int ldo;       // QKV: qkv_out [M, N]; RES: x [M, N] (in place); ACT: out [M, ldo]; LOGITS: logits or NULL

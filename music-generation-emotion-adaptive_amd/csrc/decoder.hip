@@ -109,6 +109,13 @@ struct mgea_decoder {
     // index 4 * layer + {0 in_proj, 1 out_proj, 2 fc1, 3 fc2}, then the head
     float* wt = nullptr;
     std::vector<int64_t> wt_off;
+    // LayerNorm folded into in_proj (ln1) and fc1 (ln2): those two tiled matrices hold gamma * W, and lnv holds per layer
+    // [c1 3C][c2 3C][c1 F][c2 F] (common.h: launch_ln_fold)
+    float* lnv = nullptr;
+    const float* qkv_c1(int l) const { return lnv + (int64_t)l * (6 * cfg.d_model + 2 * cfg.d_ff); }
+    const float* qkv_c2(int l) const { return qkv_c1(l) + 3 * cfg.d_model; }
+    const float* fc1_c1(int l) const { return qkv_c1(l) + 6 * cfg.d_model; }
+    const float* fc1_c2(int l) const { return fc1_c1(l) + cfg.d_ff; }
     const float* tw(int layer, int j) const { return wt + wt_off[4 * layer + j]; }
     const float* head_tw() const { return wt + wt_off[4 * cfg.n_layer]; }
 };
@@ -314,8 +321,8 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         SkinnyArgs a{};
         a.M = M; a.eps = c.ln_eps;
         // ln1 + in_proj + KV append
-        a.A = u.x; a.lda = C; a.W = h->tw(l, 0); a.bias = h->lw(l, L_INB); a.N = 3 * C; a.K = C;
-        a.lnw = h->lw(l, L_LN1W); a.lnb = h->lw(l, L_LN1B); a.stats_in = u.stats; a.n_part = n_part; a.part_cnt = part_cnt;
+        a.A = u.x; a.lda = C; a.W = h->tw(l, 0); a.bias = h->qkv_c2(l); a.N = 3 * C; a.K = C;
+        a.ln_c1 = h->qkv_c1(l); a.stats_in = u.stats; a.n_part = n_part; a.part_cnt = part_cnt;
         a.out = u.qkv; a.ldo = 3 * C;
         a.pool = h->kv; a.layer = l; a.page_table = u.page_table; a.max_pages = h->max_pages; a.ctx_len = u.ctx_len;
         a.lens = lens; a.T = T; a.C = C;
@@ -335,8 +342,8 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         // ln2 + mlp.0 + GELU
         SkinnyArgs f{};
         f.M = M; f.eps = c.ln_eps;
-        f.A = u.x; f.lda = C; f.W = h->tw(l, 2); f.bias = h->lw(l, L_FC1B); f.N = F; f.K = C;
-        f.lnw = h->lw(l, L_LN2W); f.lnb = h->lw(l, L_LN2B); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
+        f.A = u.x; f.lda = C; f.W = h->tw(l, 2); f.bias = h->fc1_c2(l); f.N = F; f.K = C;
+        f.ln_c1 = h->fc1_c1(l); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
         f.out = u.hbuf; f.ldo = F; f.act = ACT_GELU;
         PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
         // mlp.2 + residual (+ stats for the next ln1)
@@ -584,16 +591,20 @@ static int build_tiled_weights(mgea_decoder* h, hipStream_t st) {
             h->wt_off.push_back(total); total += wtile_floats(C, F);
         }
         h->wt_off.push_back(total); total += wtile_floats(V, C);
-        if (hipMalloc((void**)&h->wt, (size_t)total * sizeof(float)) != hipSuccess) {
+        if (hipMalloc((void**)&h->wt, (size_t)total * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&h->lnv, (size_t)c.n_layer * (6 * C + 2 * F) * sizeof(float)) != hipSuccess) {
+            if (h->wt) (void)hipFree(h->wt);
             h->wt = nullptr;
             set_error("decoder_create: allocation of the decode-layout weights (%lld MB) failed", (long long)(total * 4 >> 20));
             return MGEA_ENOMEM;
         }
     }
     for (int l = 0; l < c.n_layer; ++l) {
-        MGEA_TRY(launch_tile_weights(h->lw(l, L_INW), 3 * C, C, h->wt + h->wt_off[4 * l + 0], st));
+        MGEA_TRY(launch_ln_fold(h->lw(l, L_INW), h->lw(l, L_LN1W), h->lw(l, L_LN1B), h->lw(l, L_INB), 3 * C, C,
+                                h->wt + h->wt_off[4 * l + 0], const_cast<float*>(h->qkv_c1(l)), const_cast<float*>(h->qkv_c2(l)), st));
         MGEA_TRY(launch_tile_weights(h->lw(l, L_OUTW), C, C, h->wt + h->wt_off[4 * l + 1], st));
-        MGEA_TRY(launch_tile_weights(h->lw(l, L_FC1W), F, C, h->wt + h->wt_off[4 * l + 2], st));
+        MGEA_TRY(launch_ln_fold(h->lw(l, L_FC1W), h->lw(l, L_LN2W), h->lw(l, L_LN2B), h->lw(l, L_FC1B), F, C,
+                                h->wt + h->wt_off[4 * l + 2], const_cast<float*>(h->fc1_c1(l)), const_cast<float*>(h->fc1_c2(l)), st));
         MGEA_TRY(launch_tile_weights(h->lw(l, L_FC2W), C, F, h->wt + h->wt_off[4 * l + 3], st));
     }
     MGEA_TRY(launch_tile_weights(h->head_w(), V, C, h->wt + h->wt_off[4 * c.n_layer], st));
@@ -697,7 +708,7 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     (void)hipDeviceSynchronize();
     drop_graph(h);
     free_ws(h);
-    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt};
+    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv};
     for (void* q : p)
         if (q) (void)hipFree(q);
     for (auto& L : h->lanes) {

@@ -20,9 +20,13 @@
 //   * v_mfma_f32_16x16x4_f32 (exact fp32), issued "swapped" so a lane owns 4 consecutive output
 //     columns; the k order inside the chain is a fixed permutation (k = k0 + 8g + 4h + s) applied
 //     to both operands; results are run-to-run bit-identical;
-//   * LN prologue: the PRODUCER of x (embedding or a residual epilogue) leaves per-row partial
-//     statistics (mean, M2) per 16-column tile; the consumer merges them with Chan's formula
-//     and normalises its A fragments in registers.
+//   * LayerNorm is folded out of the K loop: with W' = gamma * W (built with the tiled copy), c1 = sum_k W'[n,k]
+//     and c2 = sum_k beta[k] W[n,k] + bias[n],
+//         LN(x) @ W^T + bias = rstd * (x @ W'^T - mean * c1) + c2,
+//     so the loop runs on the raw x like the other kernels and nothing waits for the statistics before
+//     the MFMAs.  The PRODUCER of x (embedding or a residual epilogue) leaves per-row partial statistics
+//     (mean, M2) per 16-column tile; the consumer merges them with Chan's formula under its MFMA tail and
+//     applies (mean, rstd) in the epilogue.
 #include "common.h"
 
 namespace mgea {
@@ -44,20 +48,18 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
     // k-chunks (32 wide) a wave keeps in flight.  Measured (tools/skinny_phases.py): deeper (4, 8) does not
     // help -- a CU's vector memory path sustains only ~40-60 GB/s of L2 hits however many loads are queued
-    constexpr int DEPTH = (!LN && MT * NT == 1) ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ LN: 2*ROWS stats, 2*K gamma/beta)
+    constexpr int DEPTH = (MT * NT == 1) ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ LN: mean and rstd of the ROWS rows)
     const int NW = a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
     float* s_mean = red + NW * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
-    float* s_gam = s_rstd + ROWS;
-    float* s_bet = s_gam + a.K;
 
     // grid.x is padded to a multiple of 8 so that the workgroups sharing a W tile (same blockIdx.x, different
     // blockIdx.y) are a multiple of 8 apart in dispatch order = same XCD / same L2 (speed only)
     // The kernel-argument block (4 x 64-B lines) is read with scalar loads the compiler otherwise sinks to
     // their first use, block by block: each is a cold scalar-cache miss of several hundred ns on the critical
     // path of a ~6 us kernel.  Asking for every field here makes them ONE batch of loads and one wait.
-    asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.lnw), "s"(a.lnb), "s"(a.eps),
+    asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.ln_c1), "s"(a.eps),
                        "s"(a.stats_in), "s"(a.n_part), "s"(a.part_cnt), "s"(a.out), "s"(a.ldo), "s"(a.stats_out), "s"(a.act), "s"(a.dbg), "s"(a.nw));
     if (EPI == EPI_QKV)
         asm volatile("" :: "s"(a.pool.base), "s"(a.pool.H), "s"(a.pool.dh), "s"(a.pool.layer_stride), "s"(a.layer), "s"(a.page_table),
@@ -79,14 +81,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     const int kw = a.K / NW, kbeg = wave * kw;
     const int nchunk = kw >> 5;
 
-    // LN prologue, part 1.  A CU's vector-memory path returns loads in issue order across ALL its waves
-    // (measured: a separate statistics wave gains nothing), so the small LayerNorm loads must be the FIRST
-    // ones every wave issues: one float4 (two (mean, M2) partials of the producer's 16-column tiles) per
-    // lane, 16 lanes per row, and gamma/beta once per workgroup (they go to LDS; per-lane global loads of
-    // gamma/beta cost as many vector-memory cycles as A itself).  Everything from here to the K loop is
-    // branch-free on purpose: the compiler then waits with an exact vmcnt for these loads only and the
-    // merge runs under the flight of the operand loads.
-    float4 st0, st1, gam4, bet4;
+    // LN: the producer's per-tile (mean, M2) partials of this tile's rows, one float4 (two partials) per lane,
+    // 16 lanes per row; requested first, merged after the K loop
+    float4 st0, st1;
     int s_lr = 0, s_j = 0;
     bool s_ok = false;
     if (LN) {
@@ -96,13 +93,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         const float* sp = a.stats_in + ((int64_t)(s_ok ? m0 + s_lr : 0) * a.n_part) * 2;
         const int p0 = 2 * s_j, p1 = 32 + 2 * s_j;   // n_part <= 64 and even (host check)
         st0 = ld4(sp + 2 * (p0 < a.n_part ? p0 : 0));
-        // (no default values for the conditional loads: a select after them would wait for them right here)
-        if (a.n_part > 32) st1 = ld4(sp + 2 * (p1 < a.n_part ? p1 : 0));
-        if (4 * tid < a.K) {   // K = 512: waves 0 and 1 only
-            gam4 = ld4(a.lnw + 4 * tid);
-            bet4 = ld4(a.lnb + 4 * tid);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep these four loads ahead of the operand loads
+        st1 = ld4(sp + 2 * (p1 < a.n_part ? p1 : 0));
+        __builtin_amdgcn_sched_barrier(0);   // these two stay ahead of the operand loads (loads return in issue order)
     }
     // operands in fragment order (common.h): lane l of a wave reads bytes [16 l, 16 l + 16) of a 1 KB block.
     // A: rows >= M of the 64-row buffer hold stale data whose products are never stored
@@ -134,24 +126,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
             af[buf][mt][1] = ld4(atile[mt] + ch * 2048 + 256);
         }
     };
-    float mu[MT], rs[MT];
-    auto compute_chunk = [&](int buf, int ch) {
+    auto compute_chunk = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float4 gg, bb;
-            if (LN) {
-                gg = *reinterpret_cast<const float4*>(&s_gam[kbeg + ch * 32 + 8 * g + 4 * h]);
-                bb = *reinterpret_cast<const float4*>(&s_bet[kbeg + ch * 32 + 8 * g + 4 * h]);
-            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                float4 x = af[buf][mt][h];
-                if (LN) {
-                    x.x = (x.x - mu[mt]) * rs[mt] * gg.x + bb.x;
-                    x.y = (x.y - mu[mt]) * rs[mt] * gg.y + bb.y;
-                    x.z = (x.z - mu[mt]) * rs[mt] * gg.z + bb.z;
-                    x.w = (x.w - mu[mt]) * rs[mt] * gg.w + bb.w;
-                }
+                const float4 x = af[buf][mt][h];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 w4 = wf[buf][nt][h];
@@ -163,10 +143,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
             }
         }
     };
-    // every wave puts its first DEPTH k-chunks in flight (LN: a wave owns >= DEPTH chunks, host check)
+    // every wave puts its first DEPTH k-chunks in flight.  LN: branch-free (a short K re-reads its last chunk), so
+    // that the compiler can wait for the statistics alone -- behind a branch it would wait for every load
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (LN || d < nchunk) load_chunk(d, d);
+    for (int d = 0; d < DEPTH; ++d) {
+        if (LN) load_chunk(d, d < nchunk ? d : nchunk - 1);
+        else if (d < nchunk) load_chunk(d, d);
+    }
     // QKV epilogue, first hop of its page lookup (branch-free, behind the operand loads): where the row's
     // new token goes.  The second hop and the other epilogue operands are requested after the K loop.
     const int e_lr = tid / (4 * NT), e_q = tid % (4 * NT);   // this thread's first epilogue item
@@ -178,14 +161,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         e_len = (a.lens ? a.lens : a.ctx_len)[pb];
     }
     if (LN) {
-        __builtin_amdgcn_sched_barrier(0);   // ... and the merge (which waits for them) behind the operand loads' issue
-        // every partial covers the same number of columns (part_cnt), so
+        __builtin_amdgcn_sched_barrier(0);   // loads above, merge below: the wait for the statistics is then an exact vmcnt
+        // merge the partials while the operand loads are in flight (results are only needed in the epilogue, behind the
+        // workgroup barrier): every partial covers the same number of columns (part_cnt), so
         //   mean = average of the tile means,  M2 = sum M2_t + part_cnt * sum (mean_t - mean)^2
         const bool v0 = 2 * s_j < a.n_part, v1 = 32 + 2 * s_j < a.n_part;
         float sm = (v0 ? st0.x + st0.z : 0.f) + (v1 ? st1.x + st1.z : 0.f);
         sm = row16_sum(sm);
         const float mean = sm * (1.0f / (float)a.n_part);
-        MGEA_TS(6);
         const float cnt = (float)a.part_cnt;
         const float d0 = st0.x - mean, d1 = st0.z - mean, d2 = st1.x - mean, d3 = st1.z - mean;
         float m2 = (v0 ? (st0.y + cnt * d0 * d0) + (st0.w + cnt * d1 * d1) : 0.f) +
@@ -195,14 +178,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
             s_mean[s_lr] = s_ok ? mean : 0.f;
             s_rstd[s_lr] = s_ok ? 1.0f / sqrtf(m2 / (cnt * (float)a.n_part) + a.eps) : 0.f;
         }
-        if (4 * tid < a.K) {
-            *reinterpret_cast<float4*>(&s_gam[4 * tid]) = gam4;
-            *reinterpret_cast<float4*>(&s_bet[4 * tid]) = bet4;
-        }
-        MGEA_TS(7);
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + c]; rs[mt] = s_rstd[mt * 16 + c]; }
     }
     MGEA_TS(1);
     if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -211,7 +186,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (ch + d < nchunk) {
-                compute_chunk(d, ch + d);
+                compute_chunk(d);
                 if (ch + d + DEPTH < nchunk) load_chunk(d, ch + d + DEPTH);
             }
         }
@@ -220,10 +195,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     MGEA_TS(3);
     // the epilogue's own global operands are requested now, so that their round trip runs under the MFMA
     // drain, the LDS reduction and the barrier instead of after them
-    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_x = e_bias;
+    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_x = e_bias, e_c1 = e_bias;
     int e_phys = 0;
     if (tid < ROWS * 4 * NT) {
         if (EPI != EPI_LOGITS && a.bias) e_bias = ld4(a.bias + e_n);
+        if (LN) e_c1 = ld4(a.ln_c1 + e_n);
         if (EPI == EPI_RES && e_row < a.M) e_x = ld4(a.out + tiled_off(e_row, e_n));
         if (EPI == EPI_QKV && e_row < a.M && e_n >= a.C) {
             const int page = (e_ctx + e_row % a.T) >> 6;
@@ -256,6 +232,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
             if (w < NW) v = add4(v, pv[w]);
         const bool row_ok = row < a.M;
         const bool first = t == tid;   // the operands requested before the reduction belong to this pass
+        if (LN) {   // rstd * (x @ W'^T - mean * c1); c2 comes in as the bias
+            const float mu = s_mean[lr], rs = s_rstd[lr];
+            const float4 c1 = first ? e_c1 : ld4(a.ln_c1 + n);
+            v = make_float4(rs * (v.x - mu * c1.x), rs * (v.y - mu * c1.y), rs * (v.z - mu * c1.z), rs * (v.w - mu * c1.w));
+        }
         if (EPI != EPI_LOGITS) {
             // N % 16 == 0 for these epilogues (checked on the host)
             if (a.bias) v = add4(v, first ? e_bias : ld4(a.bias + n));
@@ -349,17 +330,17 @@ static int pick_waves(int K, bool ln, int mt) {
     // 4 threads per row of the tile.
     const int cap = 8;  // 16 waves per workgroup measured equal or slower on every decode shape
     for (int nw = cap; nw >= 1; --nw)
-        if ((K / 32) % nw == 0 && (!ln || K / 32 / nw >= 2)) return nw;   // LN: two k-chunks per wave, unconditionally in flight
+        if ((K / 32) % nw == 0) return nw;
     return 1;
 }
 
 template <int EPI, int MT, int NT = 1>
 static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
-    const bool ln = a_in.lnw != nullptr;
+    const bool ln = a_in.ln_c1 != nullptr;
     SkinnyArgs a = a_in;
     a.nw = nw;
     dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
-    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT + 2 * a.K : 0)) * sizeof(float);
+    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
     if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
     else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
     MGEA_CHECK_HIP(hipGetLastError());
@@ -368,7 +349,7 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
 
 template <int EPI>
 static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
-    const bool ln = a.lnw != nullptr;
+    const bool ln = a.ln_c1 != nullptr;
     MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
@@ -384,8 +365,8 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= 8, MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
     MGEA_REQUIRE(!ln || a.n_part <= 64, MGEA_EINVAL, "skinny gemm: more than 64 LayerNorm partials per row (%d)", a.n_part);
     MGEA_REQUIRE(!ln || a.n_part % 2 == 0, MGEA_EINVAL, "skinny gemm: odd number of LayerNorm partials per row (%d)", a.n_part);
-    MGEA_REQUIRE(!ln || (nw * 64 >= 16 * mt * 16 && a.K <= 4 * 64 * nw && a.K / 32 / nw >= 2), MGEA_EINVAL,
-                 "skinny gemm: LN prologue needs 16 lanes per tile row, K/4 lanes for gamma/beta and two k-chunks per wave (K=%d, %d-row tiles, %d waves)", a.K, 16 * mt, nw);
+    MGEA_REQUIRE(!ln || nw * 64 >= 16 * mt * 16, MGEA_EINVAL,
+                 "skinny gemm: the LayerNorm merge needs 16 lanes per tile row (K=%d, %d-row tiles, %d waves)", a.K, 16 * mt, nw);
     switch (mt) {
         case 1: return launch_skinny_mt<EPI, 1>(a, nw, st);
         case 2: return launch_skinny_mt<EPI, 2>(a, nw, st);
@@ -411,8 +392,8 @@ int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------
 // W [N, K] row-major -> fragment-ordered tiles (common.h); one thread per float4 of the output
-__global__ __launch_bounds__(256) void tile_weights_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ out,
-                                                           int64_t n_f4) {
+__global__ __launch_bounds__(256) void tile_weights_kernel(const float* __restrict__ W, const float* __restrict__ gamma, int N, int K,
+                                                           float* __restrict__ out, int64_t n_f4) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= n_f4) return;
     const int64_t blk = o >> 7;            // (tile, chunk) block of 128 float4
@@ -422,14 +403,51 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const float* __restri
     const int kc = (int)(blk % chunks);
     const int64_t n = tile * 16 + c;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) v = ld4(W + n * K + kc * 32 + 8 * g + 4 * h);
+    const int k = kc * 32 + 8 * g + 4 * h;
+    if (n < N) v = ld4(W + n * K + k);
+    if (gamma) {   // folded LayerNorm: the same fp32 products ln_fold_vectors_kernel sums
+        const float4 gm = ld4(gamma + k);
+        v = make_float4(v.x * gm.x, v.y * gm.y, v.z * gm.z, v.w * gm.w);
+    }
     st4(out + o * 4, v);
 }
 
-int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st) {
+int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st, const float* gamma) {
     MGEA_REQUIRE(W && out && N >= 1 && K >= 32 && K % 32 == 0, MGEA_EINVAL, "tile_weights: N=%d K=%d (K must be a multiple of 32)", N, K);
     const int64_t n_f4 = wtile_floats(N, K) / 4;
-    hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_f4 + 255) / 256)), dim3(256), 0, st, W, N, K, out, n_f4);
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_f4 + 255) / 256)), dim3(256), 0, st, W, gamma, N, K, out, n_f4);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// c1[n] = sum_k fl(gamma[k] * W[n,k]),  c2[n] = sum_k beta[k] * W[n,k] + bias[n]; one wave per row, fp64 sums
+__global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
+                                                              float* __restrict__ c1, float* __restrict__ c2) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(int64_t)n * K + k];
+        s1 += (double)(w * gamma[k]);
+        s2 += (double)w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+        c1[n] = (float)s1;
+        c2[n] = (float)(s2 + (bias ? (double)bias[n] : 0.0));
+    }
+}
+
+int launch_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, float* out,
+                   float* c1, float* c2, hipStream_t st) {
+    MGEA_REQUIRE(gamma && beta && c1 && c2, MGEA_EINVAL, "ln_fold: NULL argument");
+    MGEA_TRY(launch_tile_weights(W, N, K, out, st, gamma));
+    hipLaunchKernelGGL(ln_fold_vectors_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, W, gamma, beta, bias, N, K, c1, c2);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

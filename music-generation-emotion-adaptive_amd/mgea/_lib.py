@@ -75,7 +75,8 @@ PROTOTYPES = {
     "mgea_op_tiled_weight_floats": (C.c_int64, [_I32, _I32]),
     "mgea_op_tile_weights": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "mgea_op_tile_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
-    "mgea_op_skinny": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_fold_ln": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "mgea_op_skinny": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_sample": (C.c_int, [_P, _I32, _I32, C.POINTER(SamplerConfig), _I64, _P, _P, _P]),
 }
 

@@ -130,28 +130,42 @@ def untile_rows(t: torch.Tensor, M: int, N: int) -> torch.Tensor:
     return out
 
 
+def fold_ln(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: torch.Tensor):
+    """LayerNorm folded into the matrix it feeds -> (tiled gamma * W, c1, c2); see mgea_op_fold_ln."""
+    lib = _lib.load()
+    w, gamma, beta, bias = _dev(w.float()), _dev(gamma.float()), _dev(beta.float()), _dev(bias.float())
+    N, K = w.shape
+    wt = torch.empty(lib.mgea_op_tiled_weight_floats(N, K), dtype=torch.float32, device=w.device)
+    c1 = torch.empty(N, dtype=torch.float32, device=w.device)
+    c2 = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(lib.mgea_op_fold_ln(ptr(w), ptr(gamma), ptr(beta), ptr(bias), N, K, ptr(wt), ptr(c1), ptr(c2), stream_ptr()))
+    return wt, c1, c2
+
+
 def skinny(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
            act: int = 0, ln: Optional[tuple] = None, dbg: int = 0):
-    """The fused decode-step GEMM on row-major inputs (tiling done here): epilogue `residual` (returns
+    """The fused decode-step GEMM on row-major inputs (tiling / folding done here): epilogue `residual` (returns
     (residual + a @ w^T + bias, per-16-column (mean, M2) statistics)) or activation `act` (0 none, 1 GELU,
     2 ReLU).  ln = (gamma, beta, stats [M, K/16, 2]) applies LayerNorm to `a` from 16-column partial statistics."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
-    at, wt = tile_rows(a), tile_weights(w)
-    b = _dev(bias.float())
-    g = be = st = None
+    at = tile_rows(a)
+    c1 = st = None
     n_part = 0
     if ln is not None:
-        g, be, st = _dev(ln[0].float()), _dev(ln[1].float()), _dev(ln[2].float())
+        wt, c1, b = fold_ln(w, ln[0], ln[1], bias)
+        st = _dev(ln[2].float())
         n_part = st.shape[1]
+    else:
+        wt, b = tile_weights(w), _dev(bias.float())
     stats_out = torch.zeros(64 * (N // 16) * 2 + 4096, dtype=torch.float32, device=a.device)
     if residual is not None:
         out = tile_rows(residual)
-        check(lib.mgea_op_skinny(1, ptr(at), ptr(wt), ptr(b), ptr(g), ptr(be), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
+        check(lib.mgea_op_skinny(1, ptr(at), ptr(wt), ptr(b), ptr(c1), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
                                  M, N, K, 0, dbg, stream_ptr()))
         return untile_rows(out, M, N), stats_out[:M * (N // 16) * 2].view(M, N // 16, 2)
     out = torch.zeros(64 * N, dtype=torch.float32, device=a.device)
-    check(lib.mgea_op_skinny(2, ptr(at), ptr(wt), ptr(b), ptr(g), ptr(be), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
+    check(lib.mgea_op_skinny(2, ptr(at), ptr(wt), ptr(b), ptr(c1), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
                              M, N, K, act, dbg, stream_ptr()))
     return untile_rows(out, M, N)
