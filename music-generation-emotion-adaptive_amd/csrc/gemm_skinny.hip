@@ -46,12 +46,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int EPI, bool LN, int MT, int NT>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
+    // LDS row pitch of the partial tiles: + 4 floats, so that the 16 rows one ds_write_b128 of a wave touches do not
+    // all start in the same bank (unpadded: 8-way conflicts at 16 columns, 16-way at 32)
+    constexpr int PITCH = COLS + 4;
     // k-chunks (32 wide) a wave keeps in flight.  Measured (tools/skinny_phases.py): deeper (4, 8) does not
     // help -- a CU's vector memory path sustains only ~40-60 GB/s of L2 hits however many loads are queued
     constexpr int DEPTH = (MT * NT == 1) ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][COLS] (+ LN: mean and rstd of the ROWS rows)
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][PITCH] (+ LN: mean and rstd of the ROWS rows)
     const int NW = a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
-    float* s_mean = red + NW * ROWS * COLS;           // all LDS in ONE array (16-B aligned carve)
+    float* s_mean = red + NW * ROWS * PITCH;          // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
 
     // grid.x is padded to a multiple of 8 so that the workgroups sharing a W tile (same blockIdx.x, different
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * COLS + nt * 16 + 4 * g]) =
+            *reinterpret_cast<float4*>(&red[((wave * ROWS) + mt * 16 + c) * PITCH + nt * 16 + 4 * g]) =
                 make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
     __syncthreads();
     MGEA_TS(4);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         float4 pv[8];   // NW <= 8 (pick_waves)
 #pragma unroll
         for (int w = 0; w < 8; ++w)
-            pv[w] = w < NW ? *reinterpret_cast<const float4*>(&red[(w * ROWS + lr) * COLS + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[w] = w < NW ? *reinterpret_cast<const float4*>(&red[(w * ROWS + lr) * PITCH + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v = pv[0];
 #pragma unroll
         for (int w = 1; w < 8; ++w)
@@ -340,7 +343,7 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
     SkinnyArgs a = a_in;
     a.nw = nw;
     dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
-    const size_t shmem = ((size_t)nw * 16 * MT * 16 * NT + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
+    const size_t shmem = ((size_t)nw * 16 * MT * (16 * NT + 4) + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
     if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
     else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
     MGEA_CHECK_HIP(hipGetLastError());
