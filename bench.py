@@ -200,14 +200,14 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE run of this command's
             # eager twin (profiles/README.md): mean FETCH_SIZE x 1024 x 2 (gfx950 half-count correction)
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r1_pmc_fetch_size_full.json")
+            pmc = os.path.join(ROOT, "profiles", "r1_v6_pmc_fetch_size_full.json")
             if os.path.exists(pmc):
                 for k, v in json.load(open(pmc)).items():
                     if "attn_paged_kernel" in k:
                         traffic = v["mean"] * 1024 * 2
                         traffic_note = ("mean over all 6114 attention launches of the same generation run eagerly "
                                         "(MGEA_DECODER_NOGRAPH=1: rocprofv3 --pmc crashes under hipGraph replay); "
-                                        "the 8 % above the algorithmic bytes is whole-page reads of the last partial page")
+                                        "the 3 % above the algorithmic bytes is the whole-page K read of the first, speculative tile at contexts <= 256 and line granularity")
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_note=traffic_note, kernel="attn_paged_kernel<64>", launches=a["launches"],
                         avg_launch_us=a["ms"] * 1e3 / a["launches"],

@@ -263,3 +263,26 @@ def test_full_context_run_vs_oracle():
         if gl != w:
             first = next(i for i in range(n) if gl[i] != w[i])
             assert float(gap[b, first]) < 1e-4, f"row {b} diverged at step {first} with gap {float(gap[b, first])}"
+
+
+@pytest.mark.gpu
+def test_refresh_weights_after_arena_rewrite():
+    """The engine keeps a decode-layout copy of the matrices (tiled, LayerNorm folded in): after the arena is
+    rewritten in place, refresh_weights() must make the fused decode path follow it -- checked against a second
+    engine built from the new weights, and the stale copy must really differ."""
+    import torch
+    from mgea import synth
+    from mgea.decoder import DecoderEngine
+    geo = dict(vocab=300, seq_len=64, d_model=256, n_layer=2)
+    sd_a = synth.decoder_state_dict(11, geo["vocab"], geo["seq_len"], geo["d_model"], geo["n_layer"])
+    sd_b = synth.decoder_state_dict(12, geo["vocab"], geo["seq_len"], geo["d_model"], geo["n_layer"])
+    eng = DecoderEngine(sd_a, n_head=4, max_batch=4, max_ctx=64, device="cuda:0")
+    ref = DecoderEngine(sd_b, n_head=4, max_batch=4, max_ctx=64, device="cuda:0")
+    prompts = torch.tensor([[1, 2, 3], [7, 8, 9]], dtype=torch.int32, device="cuda:0")
+    want = ref.generate(prompts, 24, top_k=1).cpu()
+    stale = eng.generate(prompts, 24, top_k=1).cpu()
+    assert not torch.equal(stale, want)
+    eng.arena.copy_(ref.arena)
+    torch.cuda.synchronize()
+    eng.refresh_weights()
+    assert torch.equal(eng.generate(prompts, 24, top_k=1).cpu(), want)
