@@ -158,3 +158,20 @@ def test_weight_and_row_tiling_round_trip(ops):
     blk = t.view(8, 2, 2, 64, 4)
     assert torch.equal(blk[1, 1, 1, 35], w.cpu()[19, 52:56])
     assert torch.equal(blk[6, 0, 0, 5], torch.zeros(4))   # row 101 is padding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset,tol", [(0.0, 2e-5), (10.0, 1e-4), (100.0, 1e-3)])
+def test_skinny_gemm_folded_layernorm_with_row_offset(ops, offset, tol):
+    """The folded LayerNorm computes rstd * (x @ (gamma*W)^T - mean * c1) + c2: the subtraction cancels when a row's
+    mean is large against its spread.  Rows with a DC offset of `offset` standard deviations must stay within the
+    north-star logit tolerance (1e-3) -- here: the error bound grows linearly with the offset, as fp32 would predict."""
+    M, N, K = 64, 1536, 512
+    x = rnd(M, K, seed=21) * 1.7 + offset          # uniform(-1.7, 1.7): sigma ~ 1
+    w = rnd(N, K, seed=22, scale=K ** -0.5)
+    b, g, be = rnd(N, seed=23), 1 + 0.1 * rnd(K, seed=24), 0.1 * rnd(K, seed=25)
+    got = ops.skinny(x.cuda(), w.cuda(), b.cuda(), act=0, ln=(g.cuda(), be.cuda(), tile_stats(x).cuda())).cpu()
+    xd = x.double()
+    xn = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g.double() + be.double()
+    ref = xn @ w.double().T + b.double()
+    assert (got.double() - ref).abs().max().item() < tol
