@@ -586,6 +586,9 @@ __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* 
     __shared__ int s_tok, s_pos;
     __shared__ float redv[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the row's bookkeeping state is requested together with the partials (one round trip instead of two)
+    int st_step = 0, st_fed = 0, st_len = 0, st_done = 0;
+    if (tid == 0) { st_step = s.row_step[b]; st_fed = s.cur_ids[b]; st_len = s.ctx_len[b]; st_done = s.done[b]; }
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < n_tiles; i += 256) {
@@ -606,9 +609,9 @@ __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* 
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         const int tok = bi == 0x7fffffff ? 0 : bi;
         sampled[b] = tok;
-        const int step = s.row_step[b];
-        int out = -1, fed = s.cur_ids[b], len = s.ctx_len[b];
-        if (!s.done[b]) {
+        const int step = st_step;
+        int out = -1, fed = st_fed, len = st_len;
+        if (!st_done) {
             out = tok;
             fed = tok;
             s.cur_ids[b] = tok;
