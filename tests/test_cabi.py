@@ -77,3 +77,12 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f), encoding="utf-8").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f"{f} imports the oracle"
+
+
+def test_tiled_weight_size_is_host_arithmetic():
+    """mgea_op_tiled_weight_floats runs without a GPU: rows padded to a multiple of 32, K unchanged."""
+    from mgea import _lib
+    lib = _lib.load()
+    assert lib.mgea_op_tiled_weight_floats(8324, 512) == 8352 * 512
+    assert lib.mgea_op_tiled_weight_floats(512, 2048) == 512 * 2048
+    assert lib.mgea_op_tiled_weight_floats(1, 32) == 32 * 32
