@@ -135,8 +135,15 @@ struct StepState {
 int launch_logits_argmax(const float* P, int S, int64_t ps, int ldp, const float* bias, float* logits,
                          int M, int V, int32_t* argmax_out, hipStream_t st);
 // sampler over logits [B,V] (top_k != 1); writes ids[b]; probs_out optional
+// tail != NULL: the sampler also does the loop bookkeeping of the row and the NEXT step's embedding (advance_embed_row)
+struct TailArgs {
+    StepState s;
+    const float* tok_emb; const float* pos_emb;
+    float* x; float* stats;     // k-tiled residual stream and its LayerNorm partials (fused decode path)
+    int C, vocab, pos_rows, absolute_pos;
+};
 int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const int32_t* row_step_dev,
-                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st);
+                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st, const TailArgs* tail = nullptr);
 // after ids for this step are in `sampled` [B]: apply EOS/done logic, write ids_out[b, step],
 // cur_ids, ctx_len += 1, row_step += 1
 int launch_advance(const int32_t* sampled, const StepState& s, int B, hipStream_t st);
@@ -222,5 +229,70 @@ __device__ __forceinline__ float4 ldnt4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// End of a decode step for row b, by one 256-thread workgroup whose thread 0 holds the new token `tok`:
+// the sampler-loop bookkeeping of api_cache.py:179-181 (append, EOS stop) and the NEXT step's embedding
+// x[b] = tok_emb[fed] + pos_emb[pos] (k-tiled) with its LayerNorm statistics (two equal half-row partials).
+// st_* = the row's state as loaded by thread 0 at kernel start.  sh: >= 6 floats of shared scratch.
+__device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::TailArgs& t, int32_t* sampled, int st_step, int st_fed,
+                                                  int st_len, int st_done, float* sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* shi = reinterpret_cast<int*>(sh);
+    if (tid == 0) {
+        const mgea::StepState& s = t.s;
+        sampled[b] = tok;
+        int out = -1, fed = st_fed, len = st_len;
+        if (!st_done) {
+            out = tok;
+            fed = tok;
+            s.cur_ids[b] = tok;
+            len += 1;
+            s.ctx_len[b] = len;
+            if (tok == s.eos_id) {
+                s.done[b] = 1;
+                atomicAdd(s.n_done, 1);
+            }
+        }
+        if (s.ids_out && st_step < s.n_steps) s.ids_out[(int64_t)b * s.n_steps + st_step] = out;
+        s.row_step[b] = st_step + 1;
+        shi[4] = fed < 0 ? 0 : (fed >= t.vocab ? t.vocab - 1 : fed);
+        const int pos = t.absolute_pos ? len : 0;   // reference: a decode step adds pos_emb[:1] = row 0 (api_cache.py:99)
+        shi[5] = pos < t.pos_rows ? pos : t.pos_rows - 1;
+    }
+    __syncthreads();
+    const int id = shi[4], pos = shi[5];
+    const int C = t.C, nf4 = C >> 2;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nf4) {
+            v[i] = add4(ld4(t.tok_emb + (int64_t)id * C + f * 4), ld4(t.pos_emb + (int64_t)pos * C + f * 4));
+            st4(t.x + mgea::tiled_off(b, f * 4), v[i]);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    auto bsum = [&](float val) {
+        val = wave_sum(val);
+        __syncthreads();
+        if (lane == 0) sh[wave] = val;
+        __syncthreads();
+        return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    };
+    const float mean = bsum(sum) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256;
+        if (f < nf4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float m2 = bsum(q);
+    if (tid == 0) st4(t.stats + (int64_t)b * 4, make_float4(mean, 0.5f * m2, mean, 0.5f * m2));   // as embed_stats_kernel
+}
 }  // namespace mgea
 #endif

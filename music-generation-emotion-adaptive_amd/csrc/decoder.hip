@@ -396,11 +396,13 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
         PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
                                               u.sampled, B, st));
     } else {
-        PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st));
-        PROF(PC_ROWOP, launch_advance(u.sampled, step_state(h, u, sc.eos_id), B, st));
-        if (primed)
-            PROF(PC_ROWOP, launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, 1, C, V,
-                                              c.seq_len, abs_pos, st));
+        if (primed) {   // sampler + loop bookkeeping + next step's embedding in one launch
+            TailArgs t{step_state(h, u, sc.eos_id), h->w(T_TOK), h->w(T_POS), u.x, u.stats, C, V, c.seq_len, abs_pos};
+            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st, &t));
+        } else {
+            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st));
+            PROF(PC_ROWOP, launch_advance(u.sampled, step_state(h, u, sc.eos_id), B, st));
+        }
     }
     return MGEA_OK;
 }

@@ -576,19 +576,14 @@ __global__ __launch_bounds__(64) void argmax_advance_kernel(const float* __restr
 // x[row] = tok_emb[token] + pos_emb[pos] (k-tiled) and its LayerNorm partial statistics.
 __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* __restrict__ pval,
                                                                   const int32_t* __restrict__ pidx, int n_tiles,
-                                                                  StepState s, int32_t* __restrict__ sampled,
-                                                                  const float* __restrict__ tok_emb,
-                                                                  const float* __restrict__ pos_emb, float* __restrict__ x,
-                                                                  float* __restrict__ stats, int C, int vocab, int pos_rows,
-                                                                  int absolute_pos) {
+                                                                  TailArgs t, int32_t* __restrict__ sampled) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ int s_tok, s_pos;
-    __shared__ float redv[4];
+    __shared__ float sh[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the row's bookkeeping state is requested together with the partials (one round trip instead of two)
     int st_step = 0, st_fed = 0, st_len = 0, st_done = 0;
-    if (tid == 0) { st_step = s.row_step[b]; st_fed = s.cur_ids[b]; st_len = s.ctx_len[b]; st_done = s.done[b]; }
+    if (tid == 0) { st_step = t.s.row_step[b]; st_fed = t.s.cur_ids[b]; st_len = t.s.ctx_len[b]; st_done = t.s.done[b]; }
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < n_tiles; i += 256) {
@@ -604,72 +599,21 @@ __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* 
     }
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
     __syncthreads();
+    int tok = 0;
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        const int tok = bi == 0x7fffffff ? 0 : bi;
-        sampled[b] = tok;
-        const int step = st_step;
-        int out = -1, fed = st_fed, len = st_len;
-        if (!st_done) {
-            out = tok;
-            fed = tok;
-            s.cur_ids[b] = tok;
-            len += 1;
-            s.ctx_len[b] = len;
-            if (tok == s.eos_id) {
-                s.done[b] = 1;
-                atomicAdd(s.n_done, 1);
-            }
-        }
-        if (s.ids_out && step < s.n_steps) s.ids_out[(int64_t)b * s.n_steps + step] = out;
-        s.row_step[b] = step + 1;
-        s_tok = fed < 0 ? 0 : (fed >= vocab ? vocab - 1 : fed);
-        int pos = absolute_pos ? len : 0;   // reference: a decode step adds pos_emb[:1] = row 0 (api_cache.py:99)
-        s_pos = pos < pos_rows ? pos : pos_rows - 1;
+        tok = bi == 0x7fffffff ? 0 : bi;
     }
-    __syncthreads();
-    const int id = s_tok, pos = s_pos;
-    const int nf4 = C >> 2;
-    float4 v[4];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + i * 256;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < nf4) {
-            v[i] = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
-            st4(x + tiled_off(b, f * 4), v[i]);
-            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
-    }
-    auto bsum = [&](float val) {
-        val = wave_sum(val);
-        __syncthreads();
-        if (lane == 0) redv[wave] = val;
-        __syncthreads();
-        return (redv[0] + redv[1]) + (redv[2] + redv[3]);
-    };
-    const float mean = bsum(sum) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + i * 256;
-        if (f < nf4) {
-            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-    }
-    const float m2 = bsum(q);
-    if (tid == 0) st4(stats + (int64_t)b * 4, make_float4(mean, 0.5f * m2, mean, 0.5f * m2));   // as embed_stats_kernel
+    advance_embed_row(b, tok, t, sampled, st_step, st_fed, st_len, st_done, sh);
 }
 
 int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
                                 const float* tok_emb, const float* pos_emb, float* x, float* stats, int B, int C, int vocab,
                                 int pos_rows, int absolute_pos, hipStream_t st) {
     MGEA_REQUIRE(B <= 64 && C % 4 == 0 && C <= 4096, MGEA_EINVAL, "argmax+embed: bad shape");
-    hipLaunchKernelGGL(argmax_advance_embed_kernel, dim3(B), dim3(256), 0, st, pval, pidx, n_tiles, s, sampled, tok_emb, pos_emb,
-                       x, stats, C, vocab, pos_rows, absolute_pos);
+    TailArgs t{s, tok_emb, pos_emb, x, stats, C, vocab, pos_rows, absolute_pos};
+    hipLaunchKernelGGL(argmax_advance_embed_kernel, dim3(B), dim3(256), 0, st, pval, pidx, n_tiles, t, sampled);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -2,15 +2,15 @@
 //   logits / temperature -> additive -1e10 outside the top-k -> softmax -> multinomial(1)
 // plus a build-defined nucleus (top-p) cut that the reference does not have.
 //
-// One 256-thread workgroup per row; the row lives in LDS (V*4 bytes), nothing is sorted:
-//   * top-k : exact k-th largest logit by a 4-pass radix select on order-preserving uint keys
-//             (integer LDS histograms -> deterministic); kept = {logit >= k-th}.  exp(-1e10)
+// One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted:
+//   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys held in
+//             registers (integer counts -> deterministic); kept = {logit >= k-th}.  exp(-1e10)
 //             underflows to exactly 0 in fp32, so "mask then softmax" == "softmax over kept".
-//   * top-p : the nucleus {i : mass of strictly larger logits < top_p} by the same radix descent
-//             over fixed-point (2^-40) probability-mass histograms (64-bit LDS atomics ->
-//             deterministic); kept = {logit >= boundary}.
+//   * top-p : the nucleus {i : mass of strictly larger logits < top_p} by the same bisection over
+//             fixed-point (2^-40) probability masses (64-bit integer sums -> deterministic);
+//             kept = {logit >= boundary}.
 //   * draw  : u from Philox4x32-10 keyed (seed; row, step); inverse CDF over the kept set in
-//             index order (any fixed order gives the same distribution).  torch.multinomial's
+//             thread-major order (any fixed order gives the same distribution).  torch.multinomial's
 //             stream cannot be reproduced on device: equality with the reference is
 //             distributional, the pre-draw probabilities are compared exactly (probs_out).
 // top_k == 1 is the argmax path (rowops.hip, ties to the lowest id) for the ids.
@@ -35,27 +35,6 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
     }
 }
 
-__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int o) {
-    const uint32_t lo = __shfl_down((uint32_t)(v & 0xffffffffull), o, 64);
-    const uint32_t hi = __shfl_down((uint32_t)(v >> 32), o, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// inclusive suffix sum over the 256 threads: result(t) = sum of v over threads >= t
-__device__ __forceinline__ unsigned long long block_suffix_sum(unsigned long long v, unsigned long long* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long up = shfl_down_u64(v, o);
-        if (lane + o < 64) v += up;
-    }
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    for (int w = wave + 1; w < 4; ++w) v += red[w];
-    return v;
-}
-
 __device__ __forceinline__ float block_sum_f(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
@@ -64,111 +43,155 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Radix descent shared by top-k (weights = 1, target = k) and top-p (weights = fixed-point mass):
-// returns the smallest key t* present in {key >= floor_key} such that weight(keys > t*) < target.
-template <bool MASS>
-__device__ uint32_t radix_boundary(const float* sx, int V, uint32_t floor_key, unsigned long long target, float mx,
-                                   float invZ, unsigned long long* hist, unsigned long long* red,
-                                   uint32_t* s_prefix, unsigned long long* s_above, uint32_t* s_pick) {
-    const int tid = threadIdx.x;
-    if (tid == 0) { *s_prefix = 0u; *s_above = 0ull; }
-    for (int pass = 3; pass >= 0; --pass) {
-        hist[tid] = 0ull;
-        if (tid == 0) *s_pick = 0xffffffffu;
-        __syncthreads();
-        const uint32_t prefix = *s_prefix;
-        const unsigned long long above = *s_above;
-        const uint32_t himask = pass == 3 ? 0u : (0xffffffffu << ((pass + 1) * 8));
-        for (int i = tid; i < V; i += 256) {
-            const float x = sx[i];
-            const uint32_t k = fkey(x);
-            if (k >= floor_key && (k & himask) == prefix) {
-                unsigned long long w = 1ull;
-                if (MASS) w = (unsigned long long)((double)(__expf(x - mx) * invZ) * 1099511627776.0);
-                atomicAdd(&hist[(k >> (pass * 8)) & 255u], w);
-            }
-        }
-        __syncthreads();
-        const unsigned long long mine = hist[tid];
-        const unsigned long long incl = block_suffix_sum(mine, red);
-        const unsigned long long a_bin = above + (incl - mine);  // weight strictly above this bin
-        // boundary bin: the lowest non-empty bin whose top element still has weight-above < target
-        if (mine > 0ull && a_bin < target && a_bin + mine >= target) *s_pick = (uint32_t)tid;
-        __syncthreads();
-        const uint32_t first = *s_pick;
-        __syncthreads();
-        // everything fits under the target: take the lowest non-empty bin
-        if (first == 0xffffffffu && mine > 0ull) atomicMin(s_pick, (uint32_t)tid);
-        __syncthreads();
-        const uint32_t pick = *s_pick;
-        __syncthreads();
-        if ((uint32_t)tid == pick) {
-            *s_prefix = prefix | (pick << (pass * 8));
-            *s_above = a_bin;
-        }
-        __syncthreads();
-    }
-    return *s_prefix;
+// xor-butterfly sum over each aligned group of 16 lanes with DPP (a few cycles per step), then across the four groups
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    v += (uint32_t)__shfl_xor((int)v, 16, 64);
+    v += (uint32_t)__shfl_xor((int)v, 32, 64);
+    return v;
 }
 
+// Boundary search shared by top-k (weights = 1, target = k) and top-p (weights = fixed-point mass): the largest key t
+// with weight({key >= t, key >= floor_key}) >= target, i.e. the k-th largest logit / the logit at which the nucleus
+// mass is reached; floor_key if even everything weighs less than the target.  Bit-by-bit bisection of the 32-bit
+// order-preserving key over the thread's register-resident keys (0 = not a candidate): 32 counting passes, integer
+// arithmetic only -> exact and deterministic.  Counts come from wave ballots (no reduction at all); masses are summed
+// as two 20-bit halves in 32-bit lanes.  One barrier per pass (the cross-wave slots alternate with the pass parity).
+// (The first version descended a radix tree through LDS histograms; with ~8k logits sharing a handful of exponent
+// bytes its 64-bit LDS atomics serialised.)
+template <bool MASS, int MAXE>
+__device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE], const uint32_t (&whi)[MAXE], const uint32_t (&wlo)[MAXE],
+                                                    uint32_t floor_key, unsigned long long target, unsigned long long* red /* [8] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        const uint32_t lim = cand > floor_key ? cand : floor_key;   // only keys >= floor_key are candidates
+        unsigned long long mine;
+        if (MASS) {
+            uint32_t hi = 0u, lo = 0u;
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) {
+                const bool in = key[j] >= lim;
+                hi += in ? whi[j] : 0u;
+                lo += in ? wlo[j] : 0u;
+            }
+            mine = ((unsigned long long)wave_sum_u32(hi) << 20) + wave_sum_u32(lo);
+        } else {
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) cnt += (uint32_t)__popcll(__ballot(key[j] >= lim));
+            mine = cnt;
+        }
+        unsigned long long* slot = red + 4 * (bit & 1);
+        if (lane == 0) slot[wave] = mine;
+        __syncthreads();
+        if ((slot[0] + slot[1]) + (slot[2] + slot[3]) >= target) prefix = cand;
+    }
+    __syncthreads();   // the slots are reused by the caller
+    return prefix > floor_key ? prefix : floor_key;
+}
+
+// One 256-thread workgroup per row; thread t owns the logits t, t + 256, ... in registers (MAXE of them), so the row is
+// read from memory once, in one batch of loads, and never goes through LDS.
+template <int MAXE>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int V, float temperature,
                                                     int top_k, float top_p, uint64_t seed,
                                                     const int32_t* __restrict__ row_step, int64_t step_host,
-                                                    int32_t* __restrict__ ids_out, float* __restrict__ probs_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* sx = reinterpret_cast<float*>(smem);  // [V] scaled logits
-    __shared__ unsigned long long hist[256];
-    __shared__ unsigned long long red64[4];
+                                                    int32_t* __restrict__ ids_out, float* __restrict__ probs_out,
+                                                    TailArgs tail, int fuse_tail) {
+    __shared__ unsigned long long red64[8];
     __shared__ float redf[4];
-    __shared__ float s_scan[256];
-    __shared__ uint32_t s_prefix, s_pick;
-    __shared__ unsigned long long s_above;
+    __shared__ float s_scan[4];
     __shared__ int s_thread, s_choice;
+    __shared__ float sh_tail[8];
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* lg = logits + (int64_t)b * V;
-
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += 256) {
-        const float x = lg[i] / temperature;
-        sx[i] = x;
-        mx = fmaxf(mx, x);
+    int st_step = 0, st_fed = 0, st_len = 0, st_done = 0;   // the row's loop state, for the fused tail
+    if (fuse_tail && tid == 0) {
+        st_step = tail.s.row_step[b]; st_fed = tail.s.cur_ids[b]; st_len = tail.s.ctx_len[b]; st_done = tail.s.done[b];
     }
+    // the whole row is requested at once (a rolled loop pays one ~1 us round trip per 256 logits: the row was just
+    // written by the head kernel and sits in another XCD's L2 / the Infinity Cache)
+    float x[MAXE];
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        const int i = tid + 256 * j;
+        x[j] = i < V ? lg[i] : -INFINITY;
+    }
+    float mx = -INFINITY;
+    if (temperature != 1.0f) {   // logits / temperature (api_cache.py:170); x / 1 is x
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) x[j] = x[j] / temperature;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) mx = fmaxf(mx, x[j]);
     mx = wave_max(mx);
     if ((tid & 63) == 0) redf[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
 
+    uint32_t key[MAXE], whi[MAXE], wlo[MAXE];
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        key[j] = (tid + 256 * j < V) ? fkey(x[j]) : 0u;   // 0 = below every candidate
+        whi[j] = wlo[j] = 0u;
+    }
     uint32_t keep_key = 0u;  // keep everything
-    if (top_k > 0 && top_k < V)
-        keep_key = radix_boundary<false>(sx, V, 0u, (unsigned long long)top_k, mx, 0.f, hist, red64, &s_prefix,
-                                         &s_above, &s_pick);
+    if (top_k > 0 && top_k < V) keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64);
     if (top_p > 0.f && top_p < 1.f) {
         float z = 0.f;
-        for (int i = tid; i < V; i += 256) z += (fkey(sx[i]) >= keep_key) ? __expf(sx[i] - mx) : 0.f;
-        const float Z = block_sum_f(z, redf);
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) z += (key[j] != 0u && key[j] >= keep_key) ? __expf(x[j] - mx) : 0.f;
+        const float invZ = 1.0f / block_sum_f(z, redf);
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) {
+            if (key[j] != 0u && key[j] >= keep_key) {
+                const unsigned long long w = (unsigned long long)((double)(__expf(x[j] - mx) * invZ) * 1099511627776.0);
+                whi[j] = (uint32_t)(w >> 20);   // <= 2^20: 64 lanes x MAXE of them stay below 2^32
+                wlo[j] = (uint32_t)(w & 0xFFFFFu);
+            }
+        }
         const unsigned long long target = (unsigned long long)((double)top_p * 1099511627776.0);
-        keep_key = radix_boundary<true>(sx, V, keep_key, target, mx, 1.0f / Z, hist, red64, &s_prefix, &s_above,
-                                        &s_pick);
+        keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
     }
 
-    // ---- final distribution over the kept set, chunked by thread in index order
-    const int chunk = (V + 255) / 256;
-    const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
+    // ---- final distribution over the kept set; CDF order = thread-major (t, then t + 256, ...): any fixed order gives
+    // the same distribution
+    float e[MAXE];
     float loc = 0.f;
-    for (int i = i0; i < i1; ++i) loc += (fkey(sx[i]) >= keep_key) ? __expf(sx[i] - mx) : 0.f;
-    s_scan[tid] = loc;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        e[j] = (key[j] != 0u && key[j] >= keep_key) ? __expf(x[j] - mx) : 0.f;
+        loc += e[j];
+    }
+    // exclusive prefix of the per-thread masses in thread order: a fixed tree (wave scan, then the four wave totals left
+    // to right) -> deterministic
+    float inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += up;
+    }
+    if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
     if (tid == 0) { s_thread = -1; s_choice = -1; }
     __syncthreads();
-    float pre = 0.f, total = 0.f;
-    for (int t = 0; t < 256; ++t) {
-        if (t == tid) pre = total;
-        total += s_scan[t];
+    float wpre = 0.f, total = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w == (tid >> 6)) wpre = total;
+        total += s_scan[w];
     }
+    const float pre = wpre + (inc - loc);
     if (probs_out) {
         const float inv = 1.0f / total;
-        for (int i = tid; i < V; i += 256)
-            probs_out[(int64_t)b * V + i] = (fkey(sx[i]) >= keep_key) ? __expf(sx[i] - mx) * inv : 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j)
+            if (tid + 256 * j < V) probs_out[(int64_t)b * V + tid + 256 * j] = e[j] * inv;
     }
     if (!ids_out) return;
     uint32_t ctr[4] = {(uint32_t)b, (uint32_t)(row_step ? row_step[b] : (int32_t)step_host),
@@ -181,29 +204,35 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (tid == s_thread) {
         float acc = pre;
         int pick = -1, last = -1;
-        for (int i = i0; i < i1; ++i) {
-            if (fkey(sx[i]) >= keep_key) {
-                const float e = __expf(sx[i] - mx);
-                if (e > 0.f) {
-                    last = i;
-                    acc += e;
-                    if (acc > target) { pick = i; break; }
-                }
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j) {
+            if (e[j] > 0.f && pick < 0) {
+                last = j;
+                acc += e[j];
+                if (acc > target) pick = j;
             }
         }
-        s_choice = pick >= 0 ? pick : last;
+        const int jj = pick >= 0 ? pick : last;
+        s_choice = jj >= 0 ? tid + 256 * jj : -1;
     }
     __syncthreads();
-    if (tid == 0) ids_out[b] = s_choice >= 0 ? s_choice : 0;
+    const int tok = s_choice >= 0 ? s_choice : 0;
+    if (fuse_tail) advance_embed_row(b, tok, tail, ids_out, st_step, st_fed, st_len, st_done, sh_tail);   // writes ids_out[b] too
+    else if (tid == 0) ids_out[b] = tok;
 }
 
 int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const int32_t* row_step_dev,
-                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st) {
+                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st, const TailArgs* tail) {
     MGEA_REQUIRE(s.temperature > 0.f, MGEA_EINVAL, "sampler: temperature must be > 0");
-    MGEA_REQUIRE(V > 0 && V <= 14336, MGEA_EINVAL, "sampler: vocab %d exceeds the LDS row buffer (14336)", V);
-    const size_t shmem = (size_t)round_up(V, 64) * sizeof(float);
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), shmem, st, logits, V, s.temperature, s.top_k, s.top_p,
-                       (uint64_t)s.seed, row_step_dev, step_host, ids_out, probs_out);
+    MGEA_REQUIRE(V > 0 && V <= 14336, MGEA_EINVAL, "sampler: vocab %d exceeds the register-resident row (14336)", V);
+    MGEA_REQUIRE(!tail || (ids_out && tail->C % 4 == 0 && tail->C <= 4096), MGEA_EINVAL, "sampler: bad fused-tail arguments");
+    const TailArgs t = tail ? *tail : TailArgs{};
+    if (V <= 256 * 36)
+        hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(256), 0, st, logits, V, s.temperature, s.top_k, s.top_p, (uint64_t)s.seed,
+                           row_step_dev, step_host, ids_out, probs_out, t, tail ? 1 : 0);
+    else
+        hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(256), 0, st, logits, V, s.temperature, s.top_k, s.top_p, (uint64_t)s.seed,
+                           row_step_dev, step_host, ids_out, probs_out, t, tail ? 1 : 0);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -13,7 +13,8 @@ eng = DecoderEngine(sd, n_head=8, max_batch=64, max_ctx=TL)
 BATCHES = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64]
 for B in BATCHES:
     prompts = torch.from_numpy(synth.integers(1, "p", (B, Tp), 0, 8324)).to(torch.int32).cuda()
-    eng.generate(prompts, TL - Tp, top_k=1); torch.cuda.synchronize()
-    t0 = time.perf_counter(); eng.generate(prompts, TL - Tp, top_k=1); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f"B={B:3d}: {dt*1e3:7.1f} ms per generation, {dt/(TL-Tp)*1e6:6.1f} us per step, {B*(TL-Tp)/dt:9.0f} tokens/s", flush=True)
+    for mode, kw in (("greedy", dict(top_k=1)), ("top-k 50 (reference default)", dict(top_k=50, seed=3)), ("top-p 0.9", dict(top_k=None, top_p=0.9, seed=3))):
+        eng.generate(prompts, TL - Tp, **kw); torch.cuda.synchronize()
+        t0 = time.perf_counter(); eng.generate(prompts, TL - Tp, **kw); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"B={B:3d} {mode:30s}: {dt*1e3:7.1f} ms per generation, {dt/(TL-Tp)*1e6:6.1f} us per step, {B*(TL-Tp)/dt:9.0f} tokens/s", flush=True)
