@@ -286,3 +286,27 @@ def test_refresh_weights_after_arena_rewrite():
     torch.cuda.synchronize()
     eng.refresh_weights()
     assert torch.equal(eng.generate(prompts, 24, top_k=1).cpu(), want)
+
+
+@pytest.mark.gpu
+def test_fused_path_step_logits_vs_oracle(golden):
+    """Decoder-S geometry takes the fused decode path (fragment-ordered operands, LayerNorm folded into the matrices,
+    paged attention): its per-step logits against the oracle's, 40 teacher-forced greedy steps -- the bar is 1e-3
+    (north star), what the path actually achieves is asserted too."""
+    from oracle.decoder_ref import DecoderRef
+    g = golden("decoder_S")
+    eng, sd, n_head = make(g, max_batch=4)
+    ref = DecoderRef(sd, n_head)
+    prompts = prompts_of(g)[:2]
+    n = 40
+    want, sl = ref.generate_greedy(prompts, n, return_logits=True)
+    eng.reset_and_prefill(torch.tensor(prompts), want_logits=False)
+    samp = eng.sampler(1.0, 1)
+    worst = 0.0
+    for s in range(n):
+        out, lg = eng.step(None, samp, want_logits=True)
+        worst = max(worst, float((lg.cpu() - sl[:, s]).abs().max()))
+        assert out.cpu().tolist() == [want[b][len(p) + s] for b, p in enumerate(prompts)]
+    assert worst < LOGIT_TOL
+    assert worst < 2e-4, f"fused-path logits drifted: {worst}"
+    print(f"fused-path step logits: max |diff| vs oracle = {worst:.2e}")
