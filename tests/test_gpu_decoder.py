@@ -310,3 +310,24 @@ def test_fused_path_step_logits_vs_oracle(golden):
     assert worst < LOGIT_TOL
     assert worst < 2e-4, f"fused-path logits drifted: {worst}"
     print(f"fused-path step logits: max |diff| vs oracle = {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_fused_path_vs_reference_golden_decoder_s(golden):
+    """The fused decode path pinned directly by reference-generated data (tests/golden/decoder_S.npz, made by
+    make_golden.py from the reference's GPTWithKV / sample_kvcache): 48 greedy ids of four prompts bit-exact and the
+    first 64 logits of every step within the north-star tolerance."""
+    g = golden("decoder_S")
+    eng, _, _ = make(g, max_batch=4)
+    prompts = prompts_of(g)
+    out = eng.generate(prompts, 48, temperature=1.0, top_k=1).cpu()
+    for i, p in enumerate(prompts):
+        assert p + out[i].tolist() == g[f"greedy{i}"].tolist(), f"row {i} diverged from the reference"
+    samp = eng.sampler(1.0, 1)
+    eng.reset_and_prefill(torch.tensor(prompts), want_logits=False)
+    worst = 0.0
+    for s in range(48):
+        _, lg = eng.step(None, samp, want_logits=True)
+        for i in range(len(prompts)):
+            worst = max(worst, float(np.abs(lg[i, :64].cpu().numpy() - g[f"step_logits_head{i}"][s]).max()))
+    assert worst < LOGIT_TOL, worst
