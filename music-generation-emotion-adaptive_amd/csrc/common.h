@@ -178,6 +178,7 @@ struct SkinnyArgs {
     // folded LayerNorm (ln_c1 != NULL): W holds gamma * W, ln_c1 [N] = its row sums, bias = beta @ W^T + bias
     // (launch_ln_fold); per-row partial stats [64][n_part][2], each over `part_cnt` elements
     const float* ln_c1; float eps;
+    const float* ln_g; const float* ln_b;   // launch_gemv only: LayerNorm gamma / beta applied directly (W row-major, unfolded)
     const float* stats_in; int n_part; int part_cnt;
     // outputs
     float* out; int ldo;       // QKV: qkv_out [M, N]; RES: x [M, N] (in place); ACT: out [M, ldo]; LOGITS: logits or NULL
@@ -192,6 +193,9 @@ struct SkinnyArgs {
     int nw;                    // waves per workgroup (set by the launcher)
 };
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
+// M <= 2 rows (single-stream decode): wave-level dot products on the ROW-MAJOR arena weights (gemv_small.hip)
+bool gemv_shape_ok(int M, int N, int K);
+int launch_gemv(int epi, const SkinnyArgs& a, hipStream_t st);
 int skinny_logits_tiles(int M, int N);
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,

@@ -87,6 +87,7 @@ struct mgea_decoder {
     hipEvent_t fork_ev = nullptr;
     int n_lanes = 1, g_lanes = 0;
     bool no_graph = false;       // MGEA_DECODER_NOGRAPH=1: launch every step eagerly (rocprofv3 --pmc runs)
+    bool no_gemv = false;        // MGEA_DECODER_NOGEMV=1: keep the MFMA skinny GEMMs for batches of <= 2 rows too (A/B)
     bool force_unfused = false;  // MGEA_DECODER_UNFUSED=1: keep the 9-launch-per-layer path (A/B and fallback)
     int64_t slab_cap = 0;
     // graph of one decode step
@@ -313,9 +314,18 @@ bool fused_ok(const mgea_decoder* h, int M) {
     return fused_geometry(h->cfg) && M <= 64 && !h->force_unfused && h->wt;
 }
 
+// single-token decode steps of <= 2 rows (the reference's serving case is B = 1): wave-level dot products on the
+// row-major arena weights instead of 16 x 16 MFMA tiles (gemv_small.hip)
+bool gemv_ok(const mgea_decoder* h, int M, int T, const int32_t* lens, bool use_cache_attn) {
+    const auto& c = h->cfg;
+    return !h->no_gemv && T == 1 && !lens && use_cache_attn && gemv_shape_ok(M, c.d_model, c.d_model) &&
+           gemv_shape_ok(M, c.d_model, c.d_ff);
+}
+
 int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, M = B * T;
+    const bool gv = gemv_ok(h, M, T, lens, use_cache_attn);
     int n_part = 2, part_cnt = C / 2;  // the embedding kernel leaves the whole-row statistics as two equal halves
     for (int l = 0; l < c.n_layer; ++l) {
         SkinnyArgs a{};
@@ -326,7 +336,12 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         a.out = u.qkv; a.ldo = 3 * C;
         a.pool = h->kv; a.layer = l; a.page_table = u.page_table; a.max_pages = h->max_pages; a.ctx_len = u.ctx_len;
         a.lens = lens; a.T = T; a.C = C;
-        PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
+        if (gv) {
+            a.W = h->lw(l, L_INW); a.bias = h->lw(l, L_INB); a.ln_c1 = nullptr; a.ln_g = h->lw(l, L_LN1W); a.ln_b = h->lw(l, L_LN1B);
+            PROF(PC_GEMM, launch_gemv(EPI_QKV, a, st));
+        } else {
+            PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
+        }
         if (use_cache_attn) {
             PROF(PC_ATTN_PAGED, launch_attn_paged(u.qkv, h->kv, l, u.page_table, h->max_pages, u.ctx_len, lens, u.att, B, T, C, 1, st));
         } else {
@@ -337,7 +352,12 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         o.M = M; o.eps = c.ln_eps;
         o.A = u.att; o.lda = C; o.W = h->tw(l, 1); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
         o.out = u.x; o.ldo = C; o.stats_out = u.stats;
-        PROF(PC_GEMM, launch_skinny(EPI_RES, o, st));
+        if (gv) {
+            o.W = h->lw(l, L_OUTW);
+            PROF(PC_GEMM, launch_gemv(EPI_RES, o, st));
+        } else {
+            PROF(PC_GEMM, launch_skinny(EPI_RES, o, st));
+        }
         n_part = C / 16; part_cnt = 16;
         // ln2 + mlp.0 + GELU
         SkinnyArgs f{};
@@ -345,13 +365,23 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         f.A = u.x; f.lda = C; f.W = h->tw(l, 2); f.bias = h->fc1_c2(l); f.N = F; f.K = C;
         f.ln_c1 = h->fc1_c1(l); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
         f.out = u.hbuf; f.ldo = F; f.act = ACT_GELU;
-        PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
+        if (gv) {
+            f.W = h->lw(l, L_FC1W); f.bias = h->lw(l, L_FC1B); f.ln_c1 = nullptr; f.ln_g = h->lw(l, L_LN2W); f.ln_b = h->lw(l, L_LN2B);
+            PROF(PC_GEMM, launch_gemv(EPI_ACT, f, st));
+        } else {
+            PROF(PC_GEMM, launch_skinny(EPI_ACT, f, st));
+        }
         // mlp.2 + residual (+ stats for the next ln1)
         SkinnyArgs r{};
         r.M = M; r.eps = c.ln_eps;
         r.A = u.hbuf; r.lda = F; r.W = h->tw(l, 3); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
         r.out = u.x; r.ldo = C; r.stats_out = u.stats;
-        PROF(PC_GEMM, launch_skinny(EPI_RES, r, st));
+        if (gv) {
+            r.W = h->lw(l, L_FC2W);
+            PROF(PC_GEMM, launch_gemv(EPI_RES, r, st));
+        } else {
+            PROF(PC_GEMM, launch_skinny(EPI_RES, r, st));
+        }
     }
     return MGEA_OK;
 }
@@ -387,7 +417,12 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
     a.M = B; a.A = u.x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
     a.out = logits_out ? logits_out : (greedy ? nullptr : u.logits);
     a.ldo = V; a.pmax_val = u.pmax_val; a.pmax_idx = u.pmax_idx;
-    PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
+    if (gemv_ok(h, B, 1, nullptr, true) && gemv_shape_ok(B, V, C)) {   // partial count = ceil(V / 16) = skinny_logits_tiles(B <= 32, V)
+        a.W = h->head_w();
+        PROF(PC_GEMM, launch_gemv(EPI_LOGITS, a, st));
+    } else {
+        PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
+    }
     if (greedy && primed) {
         PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
                                                     u.sampled, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, C, V, c.seq_len,
@@ -631,6 +666,8 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     {
         const char* e = getenv("MGEA_DECODER_UNFUSED");
         h->force_unfused = e && e[0] == '1';
+        const char* gv = getenv("MGEA_DECODER_NOGEMV");
+        h->no_gemv = gv && gv[0] == '1';
         const char* g = getenv("MGEA_DECODER_NOGRAPH");
         h->no_graph = g && g[0] == '1';
         const char* ln = getenv("MGEA_DECODER_LANES");

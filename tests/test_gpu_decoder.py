@@ -289,15 +289,17 @@ def test_refresh_weights_after_arena_rewrite():
 
 
 @pytest.mark.gpu
-def test_fused_path_step_logits_vs_oracle(golden):
-    """Decoder-S geometry takes the fused decode path (fragment-ordered operands, LayerNorm folded into the matrices,
-    paged attention): its per-step logits against the oracle's, 40 teacher-forced greedy steps -- the bar is 1e-3
-    (north star), what the path actually achieves is asserted too."""
+@pytest.mark.parametrize("n_rows", [1, 2, 3])
+def test_fused_path_step_logits_vs_oracle(golden, n_rows):
+    """Decoder-S geometry takes the fused decode path (paged attention + either the MFMA skinny GEMMs with
+    fragment-ordered operands and LayerNorm folded into the matrices, from 3 rows, or the wave-level dot products of
+    gemv_small.hip for 1-2 rows): its per-step logits against the oracle's, 40 teacher-forced greedy steps -- the bar is
+    1e-3 (north star), what the path actually achieves is asserted too."""
     from oracle.decoder_ref import DecoderRef
     g = golden("decoder_S")
     eng, sd, n_head = make(g, max_batch=4)
     ref = DecoderRef(sd, n_head)
-    prompts = prompts_of(g)[:2]
+    prompts = prompts_of(g)[:n_rows]
     n = 40
     want, sl = ref.generate_greedy(prompts, n, return_logits=True)
     eng.reset_and_prefill(torch.tensor(prompts), want_logits=False)
@@ -331,3 +333,27 @@ def test_fused_path_vs_reference_golden_decoder_s(golden):
         for i in range(len(prompts)):
             worst = max(worst, float(np.abs(lg[i, :64].cpu().numpy() - g[f"step_logits_head{i}"][s]).max()))
     assert worst < LOGIT_TOL, worst
+
+
+@pytest.mark.gpu
+def test_single_stream_gemv_path_matches_mfma_path(golden, monkeypatch):
+    """B = 1 (the reference's serving case) runs its projections as wave-level dot products on the row-major weights;
+    MGEA_DECODER_NOGEMV=1 keeps the MFMA kernels.  Same greedy ids over 120 steps (two KV pages), logits within fp32
+    summation noise, and the reference-generated golden ids for the first 48."""
+    g = golden("decoder_S")
+    p = prompts_of(g)[0]
+    eng_v, _, _ = make(g, max_batch=2)
+    monkeypatch.setenv("MGEA_DECODER_NOGEMV", "1")
+    eng_m, _, _ = make(g, max_batch=2)
+    monkeypatch.delenv("MGEA_DECODER_NOGEMV")
+    a = eng_v.generate([p], 120, top_k=1).cpu()
+    b = eng_m.generate([p], 120, top_k=1).cpu()
+    assert torch.equal(a, b)
+    assert p + a[0].tolist()[:48] == g["greedy0"].tolist()
+    samp = eng_v.sampler(1.0, 1)
+    for e in (eng_v, eng_m):
+        e.reset_and_prefill(torch.tensor([p]), want_logits=False)
+    for _ in range(8):
+        _, lv = eng_v.step(None, samp, want_logits=True)
+        _, lm = eng_m.step(None, samp, want_logits=True)
+        assert float((lv - lm).abs().max()) < 2e-5
