@@ -154,7 +154,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_REQUIRE((int64_t)B * S <= c.max_tokens, MGEA_ECAPACITY, "B*S = %lld exceeds max_tokens %d", (long long)B * S, c.max_tokens);
     const int M = B * S, D = c.dim, Hd = c.hidden, NL = c.num_labels, dh = D / c.n_heads;
     auto gemm = [&](const float* A, int lda, const float* W, int m, int n, int k, int* Sout) -> int {
-        const int s = pick_split_k(m, n, k);
+        const int s = pick_split_k(m, n, k, h->slab_cap);
         MGEA_REQUIRE((int64_t)s * slab_floats(m, n) <= h->slab_cap, MGEA_ECAPACITY, "internal: bert slab workspace too small");
         const int rc = launch_gemm_f32(A, lda, W, k, h->slabs, m, n, k, s, st);
         if (rc < 0) return rc;
@@ -181,7 +181,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
                                   D, c.vocab, st));
     for (int l = 0; l < c.n_layers; ++l) {
-        if (M > 64) {   // bias (+ GELU below) inside the GEMM epilogue: no slab round trip
+        if (gemm_direct_epilogue_ok(M, 3 * D)) {   // bias (+ GELU below) inside the GEMM epilogue: no slab round trip
             MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, h->lw(l, BL_QKVW), D, h->lw(l, BL_QKVB), h->qkv, 3 * D, M, 3 * D, D,
                                               ACT_NONE, st));
         } else {
@@ -193,7 +193,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         MGEA_TRY(gemm(h->ctx, D, h->lw(l, BL_OUTW), M, D, D, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->h, nullptr,
                                     h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, M, D, 1, st));
-        if (M > 64) {
+        if (gemm_direct_epilogue_ok(M, Hd)) {
             MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, h->lw(l, BL_L1W), D, h->lw(l, BL_L1B), h->ffn, Hd, M, Hd, D, ACT_GELU, st));
         } else {
             MGEA_TRY(gemm(h->h, D, h->lw(l, BL_L1W), M, Hd, D, &Sk));

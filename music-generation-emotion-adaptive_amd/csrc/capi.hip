@@ -46,7 +46,7 @@ int mgea_op_gemm_f32(const float* a_dev, const float* w_dev, const float* bias_d
                      int32_t N, int32_t K, int32_t split_k, float* workspace_dev, void* stream) {
     MGEA_REQUIRE(a_dev && w_dev && out_dev && workspace_dev, MGEA_EINVAL, "op_gemm: NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    if (split_k <= 0) split_k = pick_split_k(M, N, K);
+    if (split_k <= 0) split_k = M > 64 ? 1 : pick_split_k(M, N, K);   // the caller sized the workspace for this (mgea.h)
     const int S = launch_gemm_f32(a_dev, K, w_dev, K, workspace_dev, M, N, K, split_k, st);
     if (S < 0) return S;
     return launch_bias_act(workspace_dev, S, slab_floats(M, N), (int)slab_ld(N), bias_dev, out_dev, N, M, N, ACT_NONE, st);

@@ -71,7 +71,8 @@ int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, float* P, 
 int launch_gemm_f32_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo,
                              int M, int N, int K, int act, hipStream_t st);
 // chooses split_k so the grid fills the chip (deterministic function of the shape)
-int pick_split_k(int M, int N, int K);
+int pick_split_k(int M, int N, int K, int64_t cap_floats = -1);   // cap: slab workspace of the caller (floats)
+bool gemm_direct_epilogue_ok(int M, int N);
 static inline int64_t slab_ld(int N) { return round_up(N, 64); }
 static inline int64_t slab_floats(int M, int N) { return (int64_t)M * slab_ld(N); }
 

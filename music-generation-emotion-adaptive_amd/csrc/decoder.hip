@@ -220,7 +220,7 @@ int ensure_ws(mgea_decoder* h, int64_t M) {
 
 // gemm + slab bookkeeping
 int gemm(mgea_decoder* h, const float* A, int lda, const float* W, int M, int N, int K, int* S, hipStream_t st) {
-    const int s = pick_split_k(M, N, K);
+    const int s = pick_split_k(M, N, K, h->slab_cap);
     MGEA_REQUIRE((int64_t)s * slab_floats(M, N) <= h->slab_cap, MGEA_ECAPACITY, "internal: slab workspace too small");
     ProfScope _ps(h, PC_GEMM, st);
     const int rc = launch_gemm_f32(A, lda, W, K, h->slabs, M, N, K, s, st);
@@ -263,7 +263,7 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
             PROF(PC_ROWOP, launch_bias_res_ln(h->slabs, S, slab_floats(M, C), (int)slab_ld(C), h->lw(l, L_OUTB), h->x,
                                         h->xn, h->lw(l, L_LN2W), h->lw(l, L_LN2B), c.ln_eps, M, C, 0, st));
         }
-        if (M > 64) {   // bias + activation inside the GEMM epilogue (no slab round trip)
+        if (gemm_direct_epilogue_ok((int)M, F)) {   // bias + activation inside the GEMM epilogue (no slab round trip)
             PROF(PC_GEMM, launch_gemm_f32_bias_act(post ? h->x : h->xn, C, h->lw(l, L_FC1W), C, h->lw(l, L_FC1B), h->hbuf, F, M, F,
                                                    C, post ? ACT_RELU : ACT_GELU, st));
         } else {

@@ -144,15 +144,26 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
     }
 }
 
-int pick_split_k(int M, int N, int K) {
-    // Skinny (decode) GEMMs: one 64-row tile; split K until ~2 blocks per CU are available.
+int pick_split_k(int M, int N, int K, int64_t cap_floats) {
     const int KT = K / 32;
-    if (M > 64) return 1;
-    const int tiles = ceil_div(N, 64);
     int s = 1;
-    while (tiles * s < 384 && s * 2 <= KT && s < 32) s *= 2;
+    if (M > 64) {
+        // 128 x 128 tiles: a mid-size M (a single prompt of 128 tokens, a short prefill) is only a handful of tiles --
+        // split K until the grid covers the chip (a [128, 768] x [768, 768] GEMM is 6 workgroups otherwise)
+        const int tiles = ceil_div(M, 128) * ceil_div(N, 128);
+        while (tiles * s < 256 && s * 2 <= KT && s < 16) s *= 2;
+    } else {
+        // Skinny (decode) GEMMs: one 64-row tile; split K until ~2 blocks per CU are available.
+        const int tiles = ceil_div(N, 64);
+        while (tiles * s < 384 && s * 2 <= KT && s < 32) s *= 2;
+    }
+    if (cap_floats >= 0)
+        while (s > 1 && (int64_t)s * slab_floats(M, N) > cap_floats) s /= 2;   // the caller's slab workspace
     return s;
 }
+
+// enough 128 x 128 tiles for the chip without split-K: the bias / activation epilogue can go inside the GEMM
+bool gemm_direct_epilogue_ok(int M, int N) { return M > 64 && ceil_div(M, 128) * ceil_div(N, 128) >= 128; }
 
 // Large-M GEMM with the bias / activation epilogue inside the kernel: out[M, ldo] = act(A W^T + bias).
 // Saves the slab write + read of the two-kernel form (one HBM round trip of M x N floats).
