@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict
 #pragma unroll
         for (int dt = 0; dt < DC; ++dt) {
             const int n = h * DH + dt * 16 + 4 * g;
-            float* dst = tiled_out ? out + tiled_off((int)(row0 + qrow), n) : out + (row0 + qrow) * C + n;
+            float* dst = tiled_out ? out + tiled_off((int)(row0 + qrow), n, C) : out + (row0 + qrow) * C + n;
             st4(dst, make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv));
         }
     }

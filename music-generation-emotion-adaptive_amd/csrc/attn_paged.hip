@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     load_k(wave < max_pages ? wave : max_pages - 1, 64);   // length not known yet: whole page
 
     const int n_new = lens ? lens[b] : T;
-    auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d) : out + m * C + h * DH + d; };
+    auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d, C) : out + m * C + h * DH + d; };
     if (t >= n_new) {  // padded query row: defined output, never used
         if (threadIdx.x < DH) *optr(threadIdx.x) = 0.f;
         return;

@@ -47,8 +47,12 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // feeds row c with k = k0 + 8 g + 4 h + s): one operand load instruction reads 1 KB of CONSECUTIVE bytes.
 // Measured on MI355X: a wave load whose lanes each fetch 16 B from a different 128-B line is served at about
 // one lane per clock (~16 B/clk, 36 GB/s per CU); consecutive lanes reach the 64 B/clk of the L1.
-__host__ __device__ static inline int64_t tiled_off(int row, int n) {
-    return (int64_t)(n >> 5) * 2048 + ((((row >> 4) * 2 + ((n >> 2) & 1)) * 64 + ((n >> 3) & 3) * 16 + (row & 15)) << 2) + (n & 3);
+// Rows beyond 64 (decode batches of up to MGEA_FUSED_MAX_ROWS rows) continue in further 64-row groups of 64 * N floats each.
+constexpr int MGEA_FUSED_MAX_ROWS = 256;
+__host__ __device__ static inline int64_t tiled_off(int row, int n, int N) {
+    const int r = row & 63;
+    return (int64_t)(row >> 6) * 64 * N + (int64_t)(n >> 5) * 2048 +
+           ((((r >> 4) * 2 + ((n >> 2) & 1)) * 64 + ((n >> 3) & 3) * 16 + (r & 15)) << 2) + (n & 3);
 }
 // The same idea for the weights of the skinny GEMMs (W [N, K] row-major in the arena): per (16-row tile,
 // 32-wide k-chunk) one 2 KB block [h][lane = 16 g + c][4] holding W[tile * 16 + c][chunk * 32 + 8 g + 4 h + s];
@@ -275,7 +279,7 @@ __device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::Ta
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f < nf4) {
             v[i] = add4(ld4(t.tok_emb + (int64_t)id * C + f * 4), ld4(t.pos_emb + (int64_t)pos * C + f * 4));
-            st4(t.x + mgea::tiled_off(b, f * 4), v[i]);
+            st4(t.x + mgea::tiled_off(b, f * 4, C), v[i]);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }

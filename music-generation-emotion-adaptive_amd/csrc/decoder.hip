@@ -184,6 +184,7 @@ int64_t slab_need(const mgea_decoder_config& c, int M) {
 }
 
 int ensure_ws(mgea_decoder* h, int64_t M) {
+    M = round_up(M, 64);   // the k-tiled buffers of the fused path are whole 64-row groups
     if (M <= h->ws_tokens) return MGEA_OK;
     MGEA_CHECK_HIP(hipDeviceSynchronize());
     free_ws(h);
@@ -205,9 +206,10 @@ int ensure_ws(mgea_decoder* h, int64_t M) {
     ALLOC(h->hbuf, M * F);
     ALLOC(h->slabs, slab);
     ALLOC(h->logits, (int64_t)h->cfg.max_batch * h->cfg.vocab);
-    ALLOC(h->stats, (int64_t)64 * (C / 16 + 1) * 2);
-    ALLOC(h->pmax_val, (int64_t)64 * ceil_div(h->cfg.vocab, 16));
-    if (hipMalloc((void**)&h->pmax_idx, (size_t)64 * ceil_div(h->cfg.vocab, 16) * sizeof(int32_t)) != hipSuccess) {
+    const int64_t fr = M < MGEA_FUSED_MAX_ROWS ? M : MGEA_FUSED_MAX_ROWS;   // rows of the fused path
+    ALLOC(h->stats, fr * (C / 16 + 1) * 2);
+    ALLOC(h->pmax_val, fr * ceil_div(h->cfg.vocab, 16));
+    if (hipMalloc((void**)&h->pmax_idx, (size_t)fr * ceil_div(h->cfg.vocab, 16) * sizeof(int32_t)) != hipSuccess) {
         set_error("decoder workspace: out of device memory");
         free_ws(h);
         return MGEA_ENOMEM;
@@ -311,7 +313,7 @@ bool fused_geometry(const mgea_decoder_config& c) {
     return c.block_mode == MGEA_BLOCK_PRELN_GELU && (c.d_model % 128) == 0 && c.d_model >= 256 && c.d_model <= 1024;
 }
 bool fused_ok(const mgea_decoder* h, int M) {
-    return fused_geometry(h->cfg) && M <= 64 && !h->force_unfused && h->wt;
+    return fused_geometry(h->cfg) && M <= MGEA_FUSED_MAX_ROWS && M <= h->ws_tokens && !h->force_unfused && h->wt;
 }
 
 // single-token decode steps of <= 2 rows (the reference's serving case is B = 1): wave-level dot products on the
@@ -471,7 +473,7 @@ int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* l
 struct LaneSplit { int n; int row0[4]; int rows[4]; };
 LaneSplit split_lanes(const mgea_decoder* h, int B) {
     LaneSplit sp{};
-    int n = h->n_lanes;
+    int n = B > 64 ? 1 : h->n_lanes;             // lane buffers hold 64 rows
     while (n > 1 && B / n < 8) n >>= 1;          // keep at least 8 rows per lane
     sp.n = n;
     for (int j = 0; j < n; ++j) {

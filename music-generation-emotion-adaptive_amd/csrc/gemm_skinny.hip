@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     // A: rows >= M of the 64-row buffer hold stale data whose products are never stored
     const float* atile[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) atile[mt] = a.A + tiled_off(m0 + mt * 16, kbeg) + lane * 4;
+    for (int mt = 0; mt < MT; ++mt) atile[mt] = a.A + tiled_off(m0 + mt * 16, kbeg, a.K) + lane * 4;
     const float* wtile[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     if (tid < ROWS * 4 * NT) {
         if (EPI != EPI_LOGITS && a.bias) e_bias = ld4(a.bias + e_n);
         if (LN) e_c1 = ld4(a.ln_c1 + e_n);
-        if (EPI == EPI_RES && e_row < a.M) e_x = ld4(a.out + tiled_off(e_row, e_n));
+        if (EPI == EPI_RES && e_row < a.M) e_x = ld4(a.out + tiled_off(e_row, e_n, a.N));
         if (EPI == EPI_QKV && e_row < a.M && e_n >= a.C) {
             const int page = (e_ctx + e_row % a.T) >> 6;
             if (page < a.max_pages) e_phys = a.page_table[(e_row / a.T) * a.max_pages + page];
@@ -247,10 +247,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         if (EPI == EPI_ACT) {
             if (a.act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
             if (a.act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-            if (row_ok) st4(a.out + tiled_off(row, n), v);   // hbuf is k-tiled for the FC2 kernel
+            if (row_ok) st4(a.out + tiled_off(row, n, a.N), v);   // hbuf is k-tiled for the FC2 kernel
         }
         if (EPI == EPI_RES) {
-            float* xp = a.out + tiled_off(row, n);           // residual stream x is k-tiled
+            float* xp = a.out + tiled_off(row, n, a.N);           // residual stream x is k-tiled
             if (row_ok) {
                 v = add4(v, first ? e_x : ld4(xp));
                 st4(xp, v);
@@ -353,7 +353,7 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
 template <int EPI>
 static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     const bool ln = a.ln_c1 != nullptr;
-    MGEA_REQUIRE(a.M >= 1 && a.M <= 64, MGEA_EINVAL, "skinny gemm: M=%d not in 1..64", a.M);
+    MGEA_REQUIRE(a.M >= 1 && a.M <= MGEA_FUSED_MAX_ROWS, MGEA_EINVAL, "skinny gemm: M=%d not in 1..%d", a.M, MGEA_FUSED_MAX_ROWS);
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
     if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !((a.dbg >> 8) & 0x1FF)) {
@@ -459,12 +459,12 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict_
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into the row-major matrix
     if (i >= (int64_t)M * (N >> 2)) return;
     const int row = (int)(i / (N >> 2)), n = (int)(i % (N >> 2)) * 4;
-    if (to_tiled) st4(dst + tiled_off(row, n), ld4(src + (int64_t)row * N + n));
-    else          st4(dst + (int64_t)row * N + n, ld4(src + tiled_off(row, n)));
+    if (to_tiled) st4(dst + tiled_off(row, n, N), ld4(src + (int64_t)row * N + n));
+    else          st4(dst + (int64_t)row * N + n, ld4(src + tiled_off(row, n, N)));
 }
 
 int launch_tile_rows(const float* src, float* dst, int M, int N, int to_tiled, hipStream_t st) {
-    MGEA_REQUIRE(src && dst && M >= 1 && M <= 64 && N >= 32 && N % 32 == 0, MGEA_EINVAL, "tile_rows: M=%d (1..64) N=%d (multiple of 32)", M, N);
+    MGEA_REQUIRE(src && dst && M >= 1 && M <= MGEA_FUSED_MAX_ROWS && N >= 32 && N % 32 == 0, MGEA_EINVAL, "tile_rows: M=%d (1..%d) N=%d (multiple of 32)", M, MGEA_FUSED_MAX_ROWS, N);
     const int64_t n = (int64_t)M * (N >> 2);
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, M, N, to_tiled);
     MGEA_CHECK_HIP(hipGetLastError());
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restr
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f < nf4) {
             if (real) v[i] = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
-            st4(x + tiled_off((int)m, f * 4), v[i]);
+            st4(x + tiled_off((int)m, f * 4, C), v[i]);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -526,7 +526,7 @@ int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* c
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
                        int absolute_pos, hipStream_t st) {
     MGEA_REQUIRE(C % 4 == 0 && C <= 4096, MGEA_EINVAL, "embed: d_model=%d must be a multiple of 4 and <= 4096", C);
-    MGEA_REQUIRE(B * T <= 64, MGEA_EINVAL, "embed (fused path): more than 64 rows");
+    MGEA_REQUIRE(B * T <= MGEA_FUSED_MAX_ROWS, MGEA_EINVAL, "embed (fused path): more than %d rows", MGEA_FUSED_MAX_ROWS);
     hipLaunchKernelGGL(embed_stats_kernel, dim3(B * T), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb, x, stats,
                        T, C, vocab, pos_rows, absolute_pos);
     MGEA_CHECK_HIP(hipGetLastError());
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void argmax_advance_embed_kernel(const float* 
 int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
                                 const float* tok_emb, const float* pos_emb, float* x, float* stats, int B, int C, int vocab,
                                 int pos_rows, int absolute_pos, hipStream_t st) {
-    MGEA_REQUIRE(B <= 64 && C % 4 == 0 && C <= 4096, MGEA_EINVAL, "argmax+embed: bad shape");
+    MGEA_REQUIRE(B <= MGEA_FUSED_MAX_ROWS && C % 4 == 0 && C <= 4096, MGEA_EINVAL, "argmax+embed: bad shape");
     TailArgs t{s, tok_emb, pos_emb, x, stats, C, vocab, pos_rows, absolute_pos};
     hipLaunchKernelGGL(argmax_advance_embed_kernel, dim3(B), dim3(256), 0, st, pval, pidx, n_tiles, t, sampled);
     MGEA_CHECK_HIP(hipGetLastError());

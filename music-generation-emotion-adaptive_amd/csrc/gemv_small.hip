@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(SkinnyArgs a) {
     int e_pos = 0, e_phys = -1;
     if (on) {
         if (a.bias) e_bias = a.bias[n];
-        if (EPI == EPI_RES) e_res = a.out[tiled_off(m, n)];
+        if (EPI == EPI_RES) e_res = a.out[tiled_off(m, n, a.N)];
         if (EPI == EPI_QKV && n >= a.C) {
             e_pos = a.ctx_len[m];
             if ((e_pos >> 6) < a.max_pages) e_phys = a.page_table[m * a.max_pages + (e_pos >> 6)];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(SkinnyArgs a) {
         for (int st = 0; st < KSX; ++st) {
             const int k = (st < KS ? st : 0) * 256 + lane * 4;   // steps beyond K re-read step 0 and are not used
 #pragma unroll
-            for (int m = 0; m < MR; ++m) xr[st][m] = ld4(a.A + tiled_off(m < a.M ? m : 0, k));
+            for (int m = 0; m < MR; ++m) xr[st][m] = ld4(a.A + tiled_off(m < a.M ? m : 0, k, a.K));
 #pragma unroll
             for (int j = 0; j < CW; ++j) wr[st][j] = ld4(wrow[j] + (st < KS ? st : 0) * 256);
             g[st] = ld4(a.ln_g + k);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(SkinnyArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int st = st0 + i < KS ? st0 + i : st0;
 #pragma unroll
-                for (int m = 0; m < MR; ++m) x[i][m] = ld4(a.A + tiled_off(m < a.M ? m : 0, st * 256 + lane * 4));
+                for (int m = 0; m < MR; ++m) x[i][m] = ld4(a.A + tiled_off(m < a.M ? m : 0, st * 256 + lane * 4, a.K));
 #pragma unroll
                 for (int j = 0; j < CW; ++j) w[i][j] = ld4(wrow[j] + st * 256);
             }
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(SkinnyArgs a) {
     if (EPI == EPI_ACT) {
         if (a.act == ACT_GELU) v = gelu_erf(v);
         if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-        if (on) a.out[tiled_off(m, n)] = v;
+        if (on) a.out[tiled_off(m, n, a.N)] = v;
     }
     if (EPI == EPI_RES) {
-        if (on) a.out[tiled_off(m, n)] = e_res + v;
+        if (on) a.out[tiled_off(m, n, a.N)] = e_res + v;
     }
     if (EPI == EPI_QKV) {   // decode step only: one new token per row (T = 1, no ragged lengths)
         if (on) {

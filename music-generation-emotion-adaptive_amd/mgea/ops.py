@@ -114,11 +114,11 @@ def tile_weights(w: torch.Tensor) -> torch.Tensor:
 
 
 def tile_rows(x: torch.Tensor) -> torch.Tensor:
-    """[M<=64, N] row-major -> k-tiled activation buffer (64 * N floats; rows >= M are zero)."""
+    """[M<=256, N] row-major -> k-tiled activation buffer (whole 64-row groups of 64 * N floats; rows >= M are zero)."""
     lib = _lib.load()
     x = _dev(x.float())
     M, N = x.shape
-    out = torch.zeros(64 * N, dtype=torch.float32, device=x.device)
+    out = torch.zeros((M + 63) // 64 * 64 * N, dtype=torch.float32, device=x.device)
     check(lib.mgea_op_tile_rows(ptr(x), ptr(out), M, N, 1, stream_ptr()))
     return out
 
@@ -159,13 +159,13 @@ def skinny(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, residual: Op
         n_part = st.shape[1]
     else:
         wt, b = tile_weights(w), _dev(bias.float())
-    stats_out = torch.zeros(64 * (N // 16) * 2 + 4096, dtype=torch.float32, device=a.device)
+    stats_out = torch.zeros(max(64, M) * (N // 16) * 2 + 4096, dtype=torch.float32, device=a.device)
     if residual is not None:
         out = tile_rows(residual)
         check(lib.mgea_op_skinny(1, ptr(at), ptr(wt), ptr(b), ptr(c1), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
                                  M, N, K, 0, dbg, stream_ptr()))
         return untile_rows(out, M, N), stats_out[:M * (N // 16) * 2].view(M, N // 16, 2)
-    out = torch.zeros(64 * N, dtype=torch.float32, device=a.device)
+    out = torch.zeros((M + 63) // 64 * 64 * N, dtype=torch.float32, device=a.device)
     check(lib.mgea_op_skinny(2, ptr(at), ptr(wt), ptr(b), ptr(c1), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
                              M, N, K, act, dbg, stream_ptr()))
     return untile_rows(out, M, N)

@@ -175,3 +175,27 @@ def test_skinny_gemm_folded_layernorm_with_row_offset(ops, offset, tol):
     xn = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g.double() + be.double()
     ref = xn @ w.double().T + b.double()
     assert (got.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(128, 1536, 512), (200, 512, 2048), (256, 2048, 512)])
+def test_skinny_gemm_more_than_64_rows(ops, M, N, K):
+    """Decode batches of up to 256 rows stay on the fused path: the k-tiled buffers continue in 64-row groups."""
+    x = rnd(M, K, seed=31) + 0.1
+    w = rnd(N, K, seed=32, scale=K ** -0.5)
+    b = rnd(N, seed=33)
+    if K <= 1024:
+        g, be = 1 + 0.1 * rnd(K, seed=34), 0.1 * rnd(K, seed=35)
+        got = ops.skinny(x.cuda(), w.cuda(), b.cuda(), act=1, ln=(g.cuda(), be.cuda(), tile_stats(x).cuda())).cpu()
+        xd = x.double()
+        xn = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g.double() + be.double()
+        ref = torch.nn.functional.gelu(xn @ w.double().T + b.double())
+        assert (got.double() - ref).abs().max().item() < 2e-5
+    else:
+        res = rnd(M, N, seed=36)
+        got, stats = ops.skinny(x.cuda(), w.cuda(), b.cuda(), residual=res.cuda())
+        ref = res.double() + x.double() @ w.double().T + b.double()
+        assert (got.cpu().double() - ref).abs().max().item() < 2e-5
+        assert (stats.cpu() - tile_stats(ref.float())).abs().max().item() < 1e-4
+    y = rnd(M, 768, seed=37).cuda()
+    assert torch.equal(ops.untile_rows(ops.tile_rows(y), M, 768), y)

@@ -9,8 +9,8 @@ from mgea import synth
 from mgea.decoder import DecoderEngine
 Tp, TL = 5, 1024
 sd = synth.decoder_state_dict(5, 8324, 1024, 512, 6)
-eng = DecoderEngine(sd, n_head=8, max_batch=64, max_ctx=TL)
 BATCHES = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64]
+eng = DecoderEngine(sd, n_head=8, max_batch=max(64, max(BATCHES)), max_ctx=TL)
 for B in BATCHES:
     prompts = torch.from_numpy(synth.integers(1, "p", (B, Tp), 0, 8324)).to(torch.int32).cuda()
     for mode, kw in (("greedy", dict(top_k=1)), ("top-k 50 (reference default)", dict(top_k=50, seed=3)), ("top-p 0.9", dict(top_k=None, top_p=0.9, seed=3))):
