@@ -48,7 +48,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Measured on MI355X: a wave load whose lanes each fetch 16 B from a different 128-B line is served at about
 // one lane per clock (~16 B/clk, 36 GB/s per CU); consecutive lanes reach the 64 B/clk of the L1.
 // Rows beyond 64 (decode batches of up to MGEA_FUSED_MAX_ROWS rows) continue in further 64-row groups of 64 * N floats each.
-constexpr int MGEA_FUSED_MAX_ROWS = 256;
+constexpr int MGEA_FUSED_MAX_ROWS = 512;
 __host__ __device__ static inline int64_t tiled_off(int row, int n, int N) {
     const int r = row & 63;
     return (int64_t)(row >> 6) * 64 * N + (int64_t)(n >> 5) * 2048 +

@@ -114,7 +114,7 @@ def tile_weights(w: torch.Tensor) -> torch.Tensor:
 
 
 def tile_rows(x: torch.Tensor) -> torch.Tensor:
-    """[M<=256, N] row-major -> k-tiled activation buffer (whole 64-row groups of 64 * N floats; rows >= M are zero)."""
+    """[M<=512, N] row-major -> k-tiled activation buffer (whole 64-row groups of 64 * N floats; rows >= M are zero)."""
     lib = _lib.load()
     x = _dev(x.float())
     M, N = x.shape

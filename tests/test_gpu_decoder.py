@@ -361,7 +361,7 @@ def test_single_stream_gemv_path_matches_mfma_path(golden, monkeypatch):
 
 @pytest.mark.gpu
 def test_fused_path_beyond_64_rows(golden):
-    """Decode batches of 65..256 rows stay on the fused path (the k-tiled buffers continue in 64-row groups): rows of a
+    """Decode batches of 65..512 rows stay on the fused path (the k-tiled buffers continue in 64-row groups): rows of a
     100-row batch equal the same prompts run as a 3-row batch (row independence: same kernels, other row tiles) and the
     oracle's greedy ids."""
     from oracle.decoder_ref import DecoderRef

@@ -180,7 +180,7 @@ def test_skinny_gemm_folded_layernorm_with_row_offset(ops, offset, tol):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(128, 1536, 512), (200, 512, 2048), (256, 2048, 512)])
 def test_skinny_gemm_more_than_64_rows(ops, M, N, K):
-    """Decode batches of up to 256 rows stay on the fused path: the k-tiled buffers continue in 64-row groups."""
+    """Decode batches of up to MGEA_FUSED_MAX_ROWS (512) rows stay on the fused path: the k-tiled buffers continue in 64-row groups."""
     x = rnd(M, K, seed=31) + 0.1
     w = rnd(N, K, seed=32, scale=K ** -0.5)
     b = rnd(N, seed=33)
