@@ -199,7 +199,7 @@ int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b
 /* Layouts of the fused decode path.  The skinny GEMM reads both operands in MFMA-fragment order so that
  * every wave load is 1 KB of consecutive bytes (see csrc/common.h):
  *   tile_weights: W [N,K] row-major -> out_dev [mgea_op_tiled_weight_floats(N,K)] (rows padded to 32);
- *   tile_rows:    [M<=64, N] row-major <-> the k-tiled activation buffer (64 * N floats), to_tiled != 0
+ *   tile_rows:    [M<=512, N] row-major <-> the k-tiled activation buffer (whole 64-row groups of 64 * N floats), to_tiled != 0
  *                 converts row-major -> tiled.  K % 32 == 0, N % 32 == 0. */
 int64_t mgea_op_tiled_weight_floats(int32_t N, int32_t K);
 int mgea_op_tile_weights(const float* w_dev, int32_t N, int32_t K, float* out_dev, void* stream);
@@ -208,7 +208,7 @@ int mgea_op_tile_rows(const float* src_dev, float* dst_dev, int32_t M, int32_t N
  * products, c2[n] = sum_k beta[k] * W[n,k] + bias[n], so that LN(x) @ W^T + bias = rstd * (x @ W'^T - mean * c1) + c2. */
 int mgea_op_fold_ln(const float* w_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
                     int32_t N, int32_t K, float* wt_out_dev, float* c1_out_dev, float* c2_out_dev, void* stream);
-/* Fused skinny GEMM (decode step, M <= 64): out = epilogue(A @ W^T + bias); epi 1 = residual add into out +
+/* Fused skinny GEMM (decode step, M <= 512): out = epilogue(A @ W^T + bias); epi 1 = residual add into out +
  * LayerNorm partial stats, 2 = activation (0 none, 1 GELU, 2 ReLU), 3 = LM head (logits [M,N] row-major in out_dev
  * or NULL, per-tile (max, argmax) partials in stats_out_dev).  a_dev and out_dev are k-tiled activation buffers,
  * w_dev is a tiled weight (above).  Folded LayerNorm of A when ln_c1_dev != NULL: w_dev / ln_c1_dev / bias_dev are
