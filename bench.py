@@ -123,6 +123,23 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None):
     return out
 
 
+def large_batch_extra(arena, device, B, Tp, TL):
+    from mgea import synth
+    from mgea.decoder import DecoderEngine
+    eng = DecoderEngine(None, n_head=N_HEAD, max_batch=B, max_ctx=TL, device=device, geometry=DEC, arena=arena)
+    prompts = torch.from_numpy(synth.integers(9, "prompts", (B, Tp), 0, DEC["vocab"])).to(device=device, dtype=torch.int32)
+    eng.generate(prompts, TL - Tp, temperature=1.0, top_k=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.generate(prompts, TL - Tp, temperature=1.0, top_k=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nodes = eng.stats()["graph_nodes"]
+    eng.close()
+    return {"metric": "midi_tokens_per_sec", "value": B * (TL - Tp) / dt, "unit": "tokens/s", "batch": B, "ms_per_generation": dt * 1e3,
+            "graph_nodes": nodes, "note": "same model, prompts of the same shape, greedy; not the BASELINE configuration (B = 64)"}
+
+
 def main():
     args = parse()
     from mgea import dist as mdist
@@ -242,6 +259,8 @@ def main():
         if not args.no_bert:
             line["extra"] = {"distilbert": bert_extra(device, max(2, args.steps), 1, not args.no_cpu),
                              "distilbert_bf16": bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")}
+            if world == 1:   # informational: the same generation at 4x the batch per GPU (still the fused 32-launch step)
+                line["extra"]["decoder_batch256"] = large_batch_extra(arena, device, 256, Tp, TL)
     eng.close()
     barrier()
     if rank == 0:
