@@ -323,6 +323,10 @@ static int pick_mt(int M, int N) {
     // once N/16 >= 64 tiles (QKV, FC1, head), 16 rows for the N = 512 projections; 64 rows never wins
     const int tiles_n = ceil_div(N, 16);
     int mt = tiles_n >= 64 ? 2 : 1;
+    if (M > 64) {   // more row tiles: the tallest tile (fewest re-reads of W through L2) that still leaves >= 256 workgroups
+        mt = 4;
+        while (mt > 1 && tiles_n * ceil_div(M, 16 * mt) < 256) mt /= 2;
+    }
     while (mt > 1 && 16 * (mt / 2) >= M) mt /= 2;  // never more rows than the problem has
     return mt;
 }
