@@ -136,7 +136,11 @@ def large_batch_extra(arena, device, B, Tp, TL):
     dt = time.perf_counter() - t0
     nodes = eng.stats()["graph_nodes"]
     eng.close()
+    C_, NL, V = DEC["d_model"], DEC["n_layer"], DEC["vocab"]
+    p_step = NL * (12 * C_ * C_ + 13 * C_) + V * C_ + V
+    step_bytes = sum(p_step * 4 + B * NL * 2 * C_ * 4 * (Tp + i + 1 + 1) for i in range(TL - Tp))   # as the headline's whole_step_hbm_frac
     return {"metric": "midi_tokens_per_sec", "value": B * (TL - Tp) / dt, "unit": "tokens/s", "batch": B, "ms_per_generation": dt * 1e3,
+            "whole_step_hbm_frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
             "graph_nodes": nodes, "note": "same model, prompts of the same shape, greedy; not the BASELINE configuration (B = 64)"}
 
 
