@@ -385,3 +385,18 @@ def test_fused_path_beyond_64_rows(golden):
         if gl != w:   # only acceptable at an fp32 near-tie of the oracle's own top-2 logits
             first = next(k for k in range(n) if gl[k] != w[k])
             assert float(gap[j, first]) < 1e-4, f"row {i} diverged at step {first} (gap {float(gap[j, first])})"
+
+
+@pytest.mark.gpu
+def test_ragged_prefill_beyond_64_rows(golden):
+    """A ragged batch whose prefill has more than 64 (row, token) pairs (40 prompts of 1..7 tokens, T = 7 -> 280 rows) goes
+    through the fused path in 64-row groups: every row equals the same prompt run in a small batch."""
+    g = golden("decoder_tiny8h")   # d_model 256: the smallest fused geometry
+    eng, _, _ = make(g, max_batch=40)
+    vocab = int(g["cfg"][1])
+    rs = np.random.RandomState(5)
+    prompts = [rs.randint(0, vocab, size=int(rs.randint(1, 8))).tolist() for _ in range(40)]
+    big = eng.generate(prompts, 12, top_k=1).cpu()
+    for i0 in range(0, 40, 4):
+        small = eng.generate(prompts[i0:i0 + 4], 12, top_k=1).cpu()
+        assert torch.equal(big[i0:i0 + 4], small), f"rows {i0}..{i0 + 3} depend on the batch they are in"
