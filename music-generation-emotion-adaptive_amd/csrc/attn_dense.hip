@@ -157,8 +157,9 @@ int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask
     switch (dh) {
         case 32: hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
         case 64: hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
+        case 96: hipLaunchKernelGGL(attn_dense_kernel<96>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
         default:
-            MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64)", dh);
+            MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 96)", dh);
     }
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;

@@ -26,9 +26,10 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
                                                         const int32_t* __restrict__ lens, float* __restrict__ out,
                                                         int H, int T, int C, float scale, int tiled_out) {
     constexpr int NCH = DH / 4;        // 16-byte chunks per head row
-    constexpr int TPI = 64 / NCH;      // tokens per V wave-instruction
-    constexpr int NVI = 64 / TPI;      // V wave-instructions per page (= NCH)
-    static_assert(64 % NCH == 0, "head_dim must be 16, 32, 64 or 128... (64 % (dh/4) == 0)");
+    constexpr int TPI = 64 / NCH;      // tokens per V wave-instruction (head_dim 96: 2 tokens x 24 chunks, 16 lanes idle)
+    constexpr int NVI = 64 / TPI;      // V wave-instructions per page
+    constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
+    static_assert(NCH % 2 == 0 && NCH <= 64 && 64 % TPI == 0, "head_dim must be a multiple of 8, at most 256, with 64 % (64 / (dh/4)) == 0");
     __shared__ float s_m[4], s_l[4];
     __shared__ float s_acc[4][DH];
 
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     const int64_t pf = pool.page_floats();
     const float* lbase = pool.base + layer * pool.layer_stride;
     const int g = lane / NCH, c = lane % NCH;
+    const bool v_lane = g < TPI;       // lanes past TPI * NCH (head_dim 96) take no part in PV
 
     // Software pipeline over this wave's pages: while QK^T consumes K(page) the V(page) loads are in
     // flight, and while PV consumes V(page) the K(next page) loads are -- each wave keeps 16 KiB
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         const int n_tok = len - pg * 64;   // >= 1; > 64 for a full page
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {   // rows beyond the cache end: the last cached row instead (their p is 0)
-            const int row = j * TPI + g;
+            const int row = v_lane ? j * TPI + g : 0;
             vv[j] = ldnt4(vpage + (row < n_tok ? row : n_tok - 1) * DH + c * 4);
         }
 
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         if (pg + 4 < npages) load_k(pg + 4, len - (pg + 4) * 64);  // K registers are free again: next page's K under PV
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {
-            const float pj = __shfl(p, j * TPI + g, 64);
+            const float pv = __shfl(p, j * TPI + g, 64);
+            const float pj = v_lane ? pv : 0.f;
             acc.x = fmaf(pj, vv[j].x, acc.x);
             acc.y = fmaf(pj, vv[j].y, acc.y);
             acc.z = fmaf(pj, vv[j].z, acc.z);
@@ -125,12 +128,24 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         }
     }
     // reduce the token groups g (lanes c, c+NCH, ...) and the per-lane softmax sums
+    if (POW2) {
 #pragma unroll
-    for (int o = 32; o >= NCH; o >>= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64);
-        acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64);
-        acc.w += __shfl_xor(acc.w, o, 64);
+        for (int o = 32; o >= NCH; o >>= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64);
+            acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64);
+            acc.w += __shfl_xor(acc.w, o, 64);
+        }
+    } else {   // lanes c < NCH collect the other token groups in a fixed order
+        float4 tot = acc;
+#pragma unroll
+        for (int gg = 1; gg < TPI; ++gg) {
+            tot.x += __shfl(acc.x, lane + gg * NCH, 64);
+            tot.y += __shfl(acc.y, lane + gg * NCH, 64);
+            tot.z += __shfl(acc.z, lane + gg * NCH, 64);
+            tot.w += __shfl(acc.w, lane + gg * NCH, 64);
+        }
+        acc = tot;
     }
     lsum = wave_sum(lsum);
     if (lane == 0) { s_m[wave] = mx; s_l[wave] = lsum; }
@@ -165,9 +180,10 @@ int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int
     switch (dh) {
         case 32: hipLaunchKernelGGL(attn_paged_kernel<32>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
         case 64: hipLaunchKernelGGL(attn_paged_kernel<64>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
+        case 96: hipLaunchKernelGGL(attn_paged_kernel<96>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
         case 128: hipLaunchKernelGGL(attn_paged_kernel<128>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
         default:
-            MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 128)", dh);
+            MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 96, 128)", dh);
     }
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;

@@ -46,7 +46,8 @@ int validate(const mgea_decoder_config* c) {
                  MGEA_EINVAL, "decoder config: non-positive dimension");
     MGEA_REQUIRE(c->d_model % c->n_head == 0, MGEA_EINVAL, "d_model %d not divisible by n_head %d", c->d_model, c->n_head);
     const int dh = c->d_model / c->n_head;
-    MGEA_REQUIRE(dh == 32 || dh == 64, MGEA_EINVAL, "head_dim %d not supported (32 or 64)", dh);
+    // 96 = a 768-wide checkpoint under the reference's hard-coded 8 heads (api_cache.py:112)
+    MGEA_REQUIRE(dh == 32 || dh == 64 || dh == 96, MGEA_EINVAL, "head_dim %d not supported (32, 64 or 96)", dh);
     MGEA_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, MGEA_EINVAL, "d_model and d_ff must be multiples of 32");
     MGEA_REQUIRE(c->d_model <= 4096, MGEA_EINVAL, "d_model > 4096 not supported");
     MGEA_REQUIRE(c->max_batch > 0 && c->max_ctx > 0, MGEA_EINVAL, "max_batch / max_ctx must be positive");

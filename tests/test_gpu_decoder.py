@@ -400,3 +400,29 @@ def test_ragged_prefill_beyond_64_rows(golden):
     for i0 in range(0, 40, 4):
         small = eng.generate(prompts[i0:i0 + 4], 12, top_k=1).cpu()
         assert torch.equal(big[i0:i0 + 4], small), f"rows {i0}..{i0 + 3} depend on the batch they are in"
+
+
+@pytest.mark.gpu
+def test_head_dim_96_reference_hard_coded_eight_heads():
+    """api_cache.py:112 builds GPTWithKV with n_head = 8 whatever the width: a 768-wide checkpoint means head_dim 96.
+    Prefill logits, and greedy ids of a 3-row and a 1-row batch over 70 steps (two KV pages), against the oracle."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    sd = synth.decoder_state_dict(21, 500, 128, 768, 2)
+    eng = DecoderEngine(sd, n_head=8, max_batch=4, max_ctx=128)
+    ref = DecoderRef(sd, 8)
+    prompts = [[3, 14, 15, 92, 65], [35, 89, 79, 32, 38], [46, 26, 43, 38, 32]]
+    logits = eng.reset_and_prefill(torch.tensor(prompts)).cpu()
+    want_l, _, _ = ref.forward(torch.tensor(prompts))
+    assert float((logits - want_l).abs().max()) < 1e-4
+    n = 70
+    want, sl = ref.generate_greedy(prompts, n, return_logits=True)
+    srt = sl.sort(-1).values
+    gap = srt[..., -1] - srt[..., -2]
+    for rows in ([0, 1, 2], [1]):
+        got = eng.generate([prompts[i] for i in rows], n, top_k=1).cpu()
+        for j, i in enumerate(rows):
+            gl, w = got[j].tolist(), want[i][5:]
+            if gl != w:   # only acceptable at an fp32 near-tie of the oracle's own top-2 logits
+                first = next(k for k in range(n) if gl[k] != w[k])
+                assert float(gap[i, first]) < 1e-4, f"row {i} diverged at step {first} (gap {float(gap[i, first])})"
