@@ -172,7 +172,7 @@ int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float
 int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
 int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st);
 
-// ---- fused skinny GEMM (decode step, M <= 64): gemm_skinny.hip --------------------------------
+// ---- fused skinny GEMM (decode step, M <= MGEA_FUSED_MAX_ROWS): gemm_skinny.hip --------------------------------
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
 
 struct SkinnyArgs {

@@ -308,7 +308,7 @@ Bufs lane_bufs(mgea_decoder* h, int j, int row0) {
                 h->ids_hist + (int64_t)row0 * h->ids_hist_stride, h->logits + (int64_t)row0 * h->cfg.vocab};
 }
 
-// Fused path for M = B*T <= 64 rows in the KV-cache block mode: 5 launches per layer
+// Fused path for M = B*T <= MGEA_FUSED_MAX_ROWS rows in the KV-cache block mode: 5 launches per layer
 // (gemm_skinny.hip); x carries per-row LayerNorm partial statistics between kernels.
 bool fused_geometry(const mgea_decoder_config& c) {
     return c.block_mode == MGEA_BLOCK_PRELN_GELU && (c.d_model % 128) == 0 && c.d_model >= 256 && c.d_model <= 1024;

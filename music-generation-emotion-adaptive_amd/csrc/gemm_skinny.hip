@@ -1,4 +1,4 @@
-// Fused skinny GEMM for the decode step (M <= 64 rows): out[M, N] = f(LN?(A)[M, K] @ W[N, K]^T + bias)
+// Fused skinny GEMM for the decode step (M <= 512 rows, designed around M = 64): out[M, N] = f(LN?(A)[M, K] @ W[N, K]^T + bias)
 // with the whole row epilogue inside the kernel, so a decoder layer is 5 launches
 // (QKV, attention, out-proj, FC1, FC2) instead of 9 and no split-K slab ever goes to HBM.
 //
@@ -42,7 +42,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// NT = 16-column tiles per workgroup (2 only for the LM head: 64 rows x 32 columns halves the A bytes per output)
+// NT = 16-column tiles per workgroup (2 only for the LM head: 32 columns per workgroup halve the A bytes per output)
 template <int EPI, bool LN, int MT, int NT>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // these two stay ahead of the operand loads (loads return in issue order)
     }
     // operands in fragment order (common.h): lane l of a wave reads bytes [16 l, 16 l + 16) of a 1 KB block.
-    // A: rows >= M of the 64-row buffer hold stale data whose products are never stored
+    // A: rows >= M of the last 64-row group hold stale data whose products are never stored
     const float* atile[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) atile[mt] = a.A + tiled_off(m0 + mt * 16, kbeg, a.K) + lane * 4;
@@ -361,7 +361,7 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
     if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !((a.dbg >> 8) & 0x1FF)) {
-        // LM head: 64 rows x 32 columns per workgroup (one per CU at V = 8324), W fetched from HBM once
+        // LM head: 32 rows x 32 columns per workgroup, W fetched from HBM once
         const int nw_head = pick_waves(a.K, false, 2);
         return launch_skinny_mt<EPI_LOGITS, 2, 2>(a, nw_head, st);
     }
