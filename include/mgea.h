@@ -32,8 +32,13 @@ extern "C" {
 #define MGEA_ECAPACITY  -4   /* batch or context exceeds what the handle reserved */
 #define MGEA_ENODEVICE  -5   /* no gfx950 device visible */
 
+/* Storage / arithmetic modes.  Which engine accepts which:
+ *   decoder (mgea_decoder_config.dtype): F32, F16        DistilBERT (mgea_bert_config.dtype): F32, BF16
+ * F32 is the parity mode of both (bit-exact greedy ids / labels against the reference's fp32 CPU path). */
 #define MGEA_DTYPE_F32   0   /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
-#define MGEA_DTYPE_BF16  1   /* perf mode: bf16 weights/KV, fp32 accumulate (bf16 MFMA) */
+#define MGEA_DTYPE_BF16  1   /* DistilBERT perf mode: bf16 weights + activations, fp32 accumulate (bf16 MFMA) */
+#define MGEA_DTYPE_F16   2   /* decoder perf mode: fp16 projection matrices + fp16 KV pages, fp32 accumulate (f16 MFMA),
+                                fp32 residual stream / LayerNorm / softmax / logits */
 
 #define MGEA_BLOCK_PRELN_GELU  0  /* api_cache.py:51-74 GPTBlock (KV-cache model, the default) */
 #define MGEA_BLOCK_POSTLN_RELU 1  /* generate_music/generate.py:25-35 nn.TransformerEncoder twin */
@@ -54,7 +59,7 @@ int mgea_device_count(void);
 typedef struct mgea_decoder mgea_decoder;
 
 typedef struct mgea_decoder_config {
-    int32_t vocab;      /* len(tok2id)                        api_cache.py:109 */
+    int32_t vocab;      /* len(tok2id), <= 14336 (sampler limit) api_cache.py:109 */
     int32_t seq_len;    /* rows of the position table         api_cache.py:36  */
     int32_t d_model;    /*                                    api_cache.py:37  */
     int32_t n_head;     /* reference hard-codes 8             api_cache.py:112 */
@@ -70,7 +75,8 @@ typedef struct mgea_decoder_config {
 } mgea_decoder_config;
 
 /* Sampler: replaces api_cache.py:169-178.  top_k == 1 is the greedy path (exact argmax, ties to
- * the lowest id); otherwise softmax(logits/temperature + (-1e10 outside top-k)) optionally cut
+ * the lowest id); otherwise softmax(logits/temperature + (-1e10 outside top-k)) -- exactly top_k
+ * entries survive like topk + scatter_ (api_cache.py:172-175), equal logits at the boundary by lowest id -- optionally cut
  * to the top_p nucleus, then one multinomial draw per row from a Philox4x32-10 stream keyed by
  * (seed, row, step) -- matches torch.multinomial in distribution only. */
 typedef struct mgea_sampler_config {
@@ -116,8 +122,11 @@ int mgea_decoder_step(mgea_decoder* h, const int32_t* ids_in_dev, const mgea_sam
 
 /* sample_kvcache (api_cache.py:159-184) for a batch: reset, prefill (logits dropped), then
  * n_steps decode steps, the first of which re-feeds each row's last prompt token.  The step is
- * captured once into a hipGraph and replayed.  ids_out_dev [B, n_steps] int32; entries after a
- * row's EOS are -1.  Host-synchronises only if eos_id >= 0 (to stop early once all rows ended). */
+ * captured once per (batch size, greedy | sampled) into a hipGraph and replayed; the sampler's
+ * scalars (seed, temperature, top_k, top_p, eos_id) live in device memory, so a new request with
+ * other values reuses the graph (mgea_decoder_stats counts instantiations).  ids_out_dev
+ * [B, n_steps] int32; entries after a row's EOS are -1.  Host-synchronises only if eos_id >= 0
+ * (to stop early once all rows ended). */
 int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const int32_t* lens_dev,
                           int32_t B, int32_t Tp, int32_t n_steps, const mgea_sampler_config* s,
                           int32_t* ids_out_dev, void* stream);
@@ -134,8 +143,15 @@ int mgea_decoder_profile(mgea_decoder* h, int32_t stride);
 int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* launches_by_class,
                               int32_t n_classes);
 
-/* Statistics of the last generate(): kernels per step, graph replays, splits; for bench/DESIGN. */
+/* out[0] kernels in the step graph last used, [1] graph replays of the last generate(), [2] graph
+ * captures + instantiations over the handle's lifetime, [4] graphs cached now; others 0. */
 int mgea_decoder_stats(mgea_decoder* h, int64_t* out /* [8] */);
+
+/* Token ids outside [0, vocab) make nn.Embedding raise IndexError in the reference (api_cache.py:99).
+ * Here they are clamped on the device and recorded in a sticky flag word, so that no call has to
+ * synchronise to validate its input: this call synchronises `stream`, returns the flags (bit 0 = an id
+ * was clamped since the last call) in *flags_out (host) and clears them. */
+int mgea_decoder_error_flags(mgea_decoder* h, int32_t* flags_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DistilBERT(+LoRA) classifier forward: replaces the model call inside

@@ -128,9 +128,9 @@ int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sam
     if (s->top_k == 1 && ids_out_dev) {
         MGEA_TRY(launch_logits_argmax(logits_dev, 1, 0, V, nullptr, nullptr, B, V, ids_out_dev, st));
         if (!probs_out_dev) return MGEA_OK;
-        return launch_sample(logits_dev, B, V, *s, nullptr, step, nullptr, probs_out_dev, st);
+        return launch_sample(logits_dev, B, V, *s, nullptr, nullptr, step, nullptr, probs_out_dev, st);
     }
-    return launch_sample(logits_dev, B, V, *s, nullptr, step, ids_out_dev, probs_out_dev, st);
+    return launch_sample(logits_dev, B, V, *s, nullptr, nullptr, step, ids_out_dev, probs_out_dev, st);
 }
 
 }  // extern "C"

@@ -103,9 +103,10 @@ struct KvPool {
 
 // decoder embedding: x[m] = tok_emb[ids[m]] + pos_emb[pos]; xn = LN(x) if lnw.
 // rows m = b*T + t; rows with t >= lens[b] are zero-filled.  pos = t (+ ctx_len[b] if absolute).
+// err_flag (device int32 or NULL): bit 0 is set when a real token id lies outside [0, vocab) (it is clamped).
 int launch_embed_ln(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                     const float* pos_emb, float* x, float* xn, const float* lnw, const float* lnb, float eps,
-                    int B, int T, int C, int vocab, int pos_rows, int absolute_pos, hipStream_t st);
+                    int B, int T, int C, int vocab, int pos_rows, int absolute_pos, int32_t* err_flag, hipStream_t st);
 // BERT embedding: h[m] = LN(word[ids[m]] + pos[t])
 int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
                          const float* lnb, float eps, float* h, int B, int S, int D, int vocab,
@@ -125,6 +126,18 @@ int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T,
                       int H, int dh, int tiled_out, hipStream_t st);
 
+// The sampler's scalars as the kernels read them from DEVICE memory (one 32-byte record per engine): a captured
+// decode-step graph holds only the pointer, so one graph serves every request whatever its seed / temperature /
+// top-k / top-p / EOS id (mgea_sampler_config, api_cache.py:160,204).
+struct SamplerParams {
+    float temperature; int32_t top_k; float top_p; int32_t eos_id;
+    uint32_t seed_lo, seed_hi; int32_t pad0, pad1;
+};
+static inline SamplerParams sampler_params(const mgea_sampler_config& s) {
+    return SamplerParams{s.temperature, s.top_k, s.top_p, s.eos_id, (uint32_t)s.seed, (uint32_t)(s.seed >> 32), 0, 0};
+}
+constexpr int MGEA_SAMPLER_MAX_VOCAB = 14336;   // the sampler keeps a row in registers: 256 threads x 56 logits
+
 // logits row epilogue: v = sum P + bias; optional store to logits[m, V]; greedy argmax path writes
 // next ids and advances the per-row state (see decoder.hip).
 struct StepState {
@@ -135,7 +148,9 @@ struct StepState {
     int32_t* n_done;    // [1]
     int32_t* ids_out;   // [B, n_steps] or NULL
     int32_t  n_steps;
-    int32_t  eos_id;
+    int32_t  eos_id;            // used when params == NULL
+    const SamplerParams* params;   // device record whose eos_id wins (NULL: eos_id above)
+    __host__ __device__ int eos() const { return params ? params->eos_id : eos_id; }
 };
 int launch_logits_argmax(const float* P, int S, int64_t ps, int ldp, const float* bias, float* logits,
                          int M, int V, int32_t* argmax_out, hipStream_t st);
@@ -147,8 +162,11 @@ struct TailArgs {
     float* x; float* stats;     // k-tiled residual stream and its LayerNorm partials (fused decode path)
     int C, vocab, pos_rows, absolute_pos;
 };
-int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const int32_t* row_step_dev,
-                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st, const TailArgs* tail = nullptr);
+// params_dev != NULL: the scalars come from that device record instead of `s`
+int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const SamplerParams* params_dev,
+                  const int32_t* row_step_dev, int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st,
+                  const TailArgs* tail = nullptr);
+int launch_set_sampler_params(SamplerParams* params_dev, const mgea_sampler_config& s, hipStream_t st);
 // after ids for this step are in `sampled` [B]: apply EOS/done logic, write ids_out[b, step],
 // cur_ids, ctx_len += 1, row_step += 1
 int launch_advance(const int32_t* sampled, const StepState& s, int B, hipStream_t st);
@@ -204,7 +222,7 @@ int launch_gemv(int epi, const SkinnyArgs& a, hipStream_t st);
 int skinny_logits_tiles(int M, int N);
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
-                       int absolute_pos, hipStream_t st);
+                       int absolute_pos, int32_t* err_flag, hipStream_t st);
 int launch_argmax_advance(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
                           int B, hipStream_t st);
 int launch_argmax_advance_embed(const float* pval, const int32_t* pidx, int n_tiles, const StepState& s, int32_t* sampled,
@@ -257,7 +275,7 @@ __device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::Ta
             s.cur_ids[b] = tok;
             len += 1;
             s.ctx_len[b] = len;
-            if (tok == s.eos_id) {
+            if (tok == s.eos()) {
                 s.done[b] = 1;
                 atomicAdd(s.n_done, 1);
             }

@@ -51,6 +51,9 @@ int validate(const mgea_decoder_config* c) {
     MGEA_REQUIRE(c->d_model % 32 == 0 && c->d_ff % 32 == 0, MGEA_EINVAL, "d_model and d_ff must be multiples of 32");
     MGEA_REQUIRE(c->d_model <= 4096, MGEA_EINVAL, "d_model > 4096 not supported");
     MGEA_REQUIRE(c->max_batch > 0 && c->max_ctx > 0, MGEA_EINVAL, "max_batch / max_ctx must be positive");
+    // the sampler keeps a row of logits in registers; refuse at create rather than at the first sampled generate()
+    MGEA_REQUIRE(c->vocab <= MGEA_SAMPLER_MAX_VOCAB, MGEA_EINVAL, "vocab %d exceeds the sampler's limit of %d", c->vocab,
+                 MGEA_SAMPLER_MAX_VOCAB);
     MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32, MGEA_EINVAL, "decoder dtype %d not built (f32 only in this build)", c->dtype);
     MGEA_REQUIRE(c->block_mode == MGEA_BLOCK_PRELN_GELU || c->block_mode == MGEA_BLOCK_POSTLN_RELU, MGEA_EINVAL, "bad block_mode");
     return MGEA_OK;
@@ -80,22 +83,18 @@ struct mgea_decoder {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *slabs = nullptr,
           *logits = nullptr, *stats = nullptr, *pmax_val = nullptr;
     int32_t* pmax_idx = nullptr;
-    // decode lanes: generate() may split the batch into n_lanes row groups that run the step on
-    // forked graph branches (the skinny GEMMs of one lane overlap the HBM-bound attention of another)
-    struct LaneBufs { float *x = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *stats = nullptr, *pmax_val = nullptr;
-                      int32_t* pmax_idx = nullptr; hipStream_t stream = nullptr; hipEvent_t done_ev = nullptr; };
-    LaneBufs lanes[4];
-    hipEvent_t fork_ev = nullptr;
-    int n_lanes = 1, g_lanes = 0;
     bool no_graph = false;       // MGEA_DECODER_NOGRAPH=1: launch every step eagerly (rocprofv3 --pmc runs)
     bool no_gemv = false;        // MGEA_DECODER_NOGEMV=1: keep the MFMA skinny GEMMs for batches of <= 2 rows too (A/B)
     bool force_unfused = false;  // MGEA_DECODER_UNFUSED=1: keep the 9-launch-per-layer path (A/B and fallback)
     int64_t slab_cap = 0;
-    // graph of one decode step
-    hipGraphExec_t gexec = nullptr;
-    hipGraph_t graph = nullptr;
-    int g_batch = -1;
-    mgea_sampler_config g_samp{};
+    // Captured decode-step graphs, one per (batch, greedy | sampled).  Everything a step reads besides its structure
+    // lives in device memory (per-row state, page table, and the sampler's scalars in samp_dev), so a request with a
+    // new seed / temperature / top-k / top-p / EOS id replays an existing graph: no capture, no instantiate.
+    struct GraphEntry { int batch; bool greedy; hipGraph_t graph; hipGraphExec_t exec; int64_t nodes; uint64_t last_use; };
+    std::vector<GraphEntry> graphs;
+    uint64_t use_clock = 0;
+    SamplerParams* samp_dev = nullptr;
+    int32_t* err_flag = nullptr;   // sticky device flags (bit 0: a token id outside the vocabulary was clamped)
     int64_t counters[8] = {0};
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_stride = 0;  // 0 = off; n = time every n-th decode step of generate(), run eagerly
@@ -163,12 +162,13 @@ void free_ws(mgea_decoder* h) {
     h->slab_cap = 0;
 }
 
-void drop_graph(mgea_decoder* h) {
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
-    h->gexec = nullptr;
-    h->graph = nullptr;
-    h->g_batch = -1;
+void drop_graphs(mgea_decoder* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+    h->counters[4] = 0;
 }
 
 int64_t slab_need(const mgea_decoder_config& c, int M) {
@@ -189,7 +189,7 @@ int ensure_ws(mgea_decoder* h, int64_t M) {
     if (M <= h->ws_tokens) return MGEA_OK;
     MGEA_CHECK_HIP(hipDeviceSynchronize());
     free_ws(h);
-    drop_graph(h);  // captured pointers die with the old workspace
+    drop_graphs(h);  // captured pointers die with the old workspace
     const int C = h->cfg.d_model, F = h->cfg.d_ff;
     int64_t slab = slab_need(h->cfg, (int)M);
     const int64_t s64 = slab_need(h->cfg, 64);
@@ -288,8 +288,7 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
     return MGEA_OK;
 }
 
-// Everything one fused decode pass touches besides the weights: the whole batch (main buffers) or one
-// lane (its own activation buffers, per-row state pointers offset to the lane's first row).
+// Everything one fused decode pass touches besides the weights.
 struct Bufs {
     float *x, *qkv, *att, *hbuf, *stats, *pmax_val;
     int32_t *pmax_idx, *page_table, *ctx_len, *cur_ids, *done, *row_step, *sampled, *ids_hist;
@@ -299,13 +298,6 @@ struct Bufs {
 Bufs main_bufs(mgea_decoder* h) {
     return Bufs{h->x, h->qkv, h->att, h->hbuf, h->stats, h->pmax_val, h->pmax_idx, h->page_table, h->ctx_len, h->cur_ids,
                 h->done, h->row_step, h->sampled, h->ids_hist, h->logits};
-}
-
-Bufs lane_bufs(mgea_decoder* h, int j, int row0) {
-    const auto& L = h->lanes[j];
-    return Bufs{L.x, L.qkv, L.att, L.hbuf, L.stats, L.pmax_val, L.pmax_idx, h->page_table + (int64_t)row0 * h->max_pages,
-                h->ctx_len + row0, h->cur_ids + row0, h->done + row0, h->row_step + row0, h->sampled + row0,
-                h->ids_hist + (int64_t)row0 * h->ids_hist_stride, h->logits + (int64_t)row0 * h->cfg.vocab};
 }
 
 // Fused path for M = B*T <= MGEA_FUSED_MAX_ROWS rows in the KV-cache block mode: 5 launches per layer
@@ -389,7 +381,8 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
     return MGEA_OK;
 }
 
-StepState step_state(mgea_decoder* h, const Bufs& u, int eos) {
+// pd != NULL: the EOS id (like the other sampler scalars) is read from that device record -- the captured graph's form
+StepState step_state(mgea_decoder* h, const Bufs& u, int eos, const SamplerParams* pd) {
     StepState s;
     s.cur_ids = u.cur_ids;
     s.ctx_len = u.ctx_len;
@@ -399,14 +392,17 @@ StepState step_state(mgea_decoder* h, const Bufs& u, int eos) {
     s.ids_out = u.ids_hist;
     s.n_steps = h->ids_hist_stride;
     s.eos_id = eos;
+    s.params = pd;
     return s;
 }
 
-// One fused decode step (T = 1) over the rows of `u` (the whole batch or one lane).
+// One fused decode step (T = 1) over the rows of `u`.
 // primed: x already holds the embedding (+ LN statistics) of cur_ids -- generate() keeps that invariant by
 // fusing the next step's embedding into this step's tail, so a replayed step is 32 launches.
-int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler_config& sc, float* logits_out,
-                       hipStream_t st, bool primed) {
+// pd: device-resident sampler scalars (generate()) or NULL (mgea_decoder_step: `sc` by value).  Only sc.top_k == 1
+// (greedy or not) shapes the launch sequence.
+int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler_config& sc, const SamplerParams* pd,
+                       float* logits_out, hipStream_t st, bool primed) {
     const auto& c = h->cfg;
     const int C = c.d_model, V = c.vocab;
     const bool greedy = sc.top_k == 1;
@@ -414,7 +410,7 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
     const int abs_pos = c.pos_mode == MGEA_POS_ABSOLUTE;
     if (!primed)
         PROF(PC_ROWOP, launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, 1, C, V,
-                                          c.seq_len, abs_pos, st));
+                                          c.seq_len, abs_pos, h->err_flag, st));
     MGEA_TRY(run_blocks_fused(h, u, B, 1, nullptr, true, st));
     SkinnyArgs a{};
     a.M = B; a.A = u.x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
@@ -427,101 +423,106 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
         PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
     }
     if (greedy && primed) {
-        PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
+        PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id, pd),
                                                     u.sampled, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, C, V, c.seq_len,
                                                     abs_pos, st));
     } else if (greedy) {
-        PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id),
+        PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id, pd),
                                               u.sampled, B, st));
     } else {
         if (primed) {   // sampler + loop bookkeeping + next step's embedding in one launch
-            TailArgs t{step_state(h, u, sc.eos_id), h->w(T_TOK), h->w(T_POS), u.x, u.stats, C, V, c.seq_len, abs_pos};
-            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st, &t));
+            TailArgs t{step_state(h, u, sc.eos_id, pd), h->w(T_TOK), h->w(T_POS), u.x, u.stats, C, V, c.seq_len, abs_pos};
+            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, pd, u.row_step, 0, u.sampled, nullptr, st, &t));
         } else {
-            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, u.row_step, 0, u.sampled, nullptr, st));
-            PROF(PC_ROWOP, launch_advance(u.sampled, step_state(h, u, sc.eos_id), B, st));
+            PROF(PC_SAMPLE, launch_sample(a.out, B, V, sc, pd, u.row_step, 0, u.sampled, nullptr, st));
+            PROF(PC_ROWOP, launch_advance(u.sampled, step_state(h, u, sc.eos_id, pd), B, st));
         }
     }
     return MGEA_OK;
 }
 
 // one decode step on cur_ids (T = 1) for the whole batch; logits_out optional
-int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, float* logits_out, hipStream_t st,
-                 bool primed = false) {
+int enqueue_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, const SamplerParams* pd, float* logits_out,
+                 hipStream_t st, bool primed = false) {
     const auto& c = h->cfg;
     const int C = c.d_model, V = c.vocab;
     const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
     const bool greedy = sc.top_k == 1;
-    if (fused_ok(h, B)) return enqueue_step_fused(h, main_bufs(h), B, sc, logits_out, st, primed);
+    if (fused_ok(h, B)) return enqueue_step_fused(h, main_bufs(h), B, sc, pd, logits_out, st, primed);
     const Bufs u = main_bufs(h);
     PROF(PC_ROWOP, launch_embed_ln(h->cur_ids, nullptr, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                              post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, 1, C,
-                             V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+                             V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
     MGEA_TRY(run_blocks(h, B, 1, nullptr, true, true, st));
     int S = 1;
     MGEA_TRY(gemm(h, h->x, C, h->head_w(), B, V, C, &S, st));
     float* lg = logits_out ? logits_out : (greedy ? nullptr : h->logits);
     PROF(PC_SAMPLE, launch_logits_argmax(h->slabs, S, slab_floats(B, V), (int)slab_ld(V), h->head_b(), lg, B, V,
                                   greedy ? h->sampled : nullptr, st));
-    if (!greedy) PROF(PC_SAMPLE, launch_sample(lg, B, V, sc, h->row_step, 0, h->sampled, nullptr, st));
-    PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, u, sc.eos_id), B, st));
+    if (!greedy) PROF(PC_SAMPLE, launch_sample(lg, B, V, sc, pd, h->row_step, 0, h->sampled, nullptr, st));
+    PROF(PC_ROWOP, launch_advance(h->sampled, step_state(h, u, sc.eos_id, pd), B, st));
     return MGEA_OK;
 }
 
-// The decode step of generate(): one fused pass over the whole batch, or -- with n_lanes > 1 -- one pass
-// per lane (contiguous row group), each on its own stream between a fork and a join event, so that
-// under graph capture the lanes become parallel branches.
-struct LaneSplit { int n; int row0[4]; int rows[4]; };
-LaneSplit split_lanes(const mgea_decoder* h, int B) {
-    LaneSplit sp{};
-    int n = B > 64 ? 1 : h->n_lanes;             // lane buffers hold 64 rows
-    while (n > 1 && B / n < 8) n >>= 1;          // keep at least 8 rows per lane
-    sp.n = n;
-    for (int j = 0; j < n; ++j) {
-        sp.row0[j] = (int)((int64_t)B * j / n);
-        sp.rows[j] = (int)((int64_t)B * (j + 1) / n) - sp.row0[j];
-    }
-    return sp;
-}
-
+// The decode step of generate(): x arrives primed on the fused path.
 int enqueue_gen_step(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_t st) {
-    if (!fused_ok(h, B)) return enqueue_step(h, B, sc, nullptr, st, false);
-    const LaneSplit sp = split_lanes(h, B);
-    if (sp.n == 1) return enqueue_step_fused(h, main_bufs(h), B, sc, nullptr, st, true);
-    if (h->prof_now) {   // event-timed eager step: lanes one after another on the launch stream
-        for (int j = 0; j < sp.n; ++j)
-            MGEA_TRY(enqueue_step_fused(h, lane_bufs(h, j, sp.row0[j]), sp.rows[j], sc, nullptr, st, true));
-        return MGEA_OK;
-    }
-    MGEA_CHECK_HIP(hipEventRecord(h->fork_ev, st));
-    for (int j = 0; j < sp.n; ++j) {
-        hipStream_t ls = j == 0 ? st : h->lanes[j].stream;
-        if (j > 0) MGEA_CHECK_HIP(hipStreamWaitEvent(ls, h->fork_ev, 0));
-        MGEA_TRY(enqueue_step_fused(h, lane_bufs(h, j, sp.row0[j]), sp.rows[j], sc, nullptr, ls, true));
-        if (j > 0) {
-            MGEA_CHECK_HIP(hipEventRecord(h->lanes[j].done_ev, ls));
-            MGEA_CHECK_HIP(hipStreamWaitEvent(st, h->lanes[j].done_ev, 0));
-        }
-    }
-    return MGEA_OK;
+    if (!fused_ok(h, B)) return enqueue_step(h, B, sc, h->samp_dev, nullptr, st, false);
+    return enqueue_step_fused(h, main_bufs(h), B, sc, h->samp_dev, nullptr, st, true);
 }
 
 // embedding (+ LN statistics) of cur_ids into the buffers the next generate() step will read
 int prime_gen(mgea_decoder* h, int B, hipStream_t st) {
     if (!fused_ok(h, B)) return MGEA_OK;
     const auto& c = h->cfg;
-    const LaneSplit sp = split_lanes(h, B);
-    for (int j = 0; j < sp.n; ++j) {
-        const Bufs u = sp.n == 1 ? main_bufs(h) : lane_bufs(h, j, sp.row0[j]);
-        MGEA_TRY(launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, sp.n == 1 ? B : sp.rows[j],
-                                    1, c.d_model, c.vocab, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
-    }
-    return MGEA_OK;
+    const Bufs u = main_bufs(h);
+    return launch_embed_stats(u.cur_ids, nullptr, u.ctx_len, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, 1, c.d_model, c.vocab,
+                              c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st);
 }
 
-bool same_sampler(const mgea_sampler_config& a, const mgea_sampler_config& b) {
-    return a.temperature == b.temperature && a.top_k == b.top_k && a.top_p == b.top_p && a.eos_id == b.eos_id &&
-           a.seed == b.seed;
+// The captured decode step for (B, greedy): from the cache, or captured + instantiated now (least recently used
+// entry evicted beyond MAX_GRAPHS).
+constexpr size_t MAX_GRAPHS = 8;
+int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_t st, hipGraphExec_t* out) {
+    const bool greedy = sc.top_k == 1;
+    for (auto& g : h->graphs)
+        if (g.batch == B && g.greedy == greedy) {
+            g.last_use = ++h->use_clock;
+            h->counters[0] = g.nodes;
+            *out = g.exec;
+            return MGEA_OK;
+        }
+    if (h->graphs.size() >= MAX_GRAPHS) {
+        size_t lru = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i)
+            if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+        MGEA_CHECK_HIP(hipStreamSynchronize(st));   // an evicted exec may still be replaying
+        (void)hipGraphExecDestroy(h->graphs[lru].exec);
+        (void)hipGraphDestroy(h->graphs[lru].graph);
+        h->graphs.erase(h->graphs.begin() + (long)lru);
+    }
+    MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_gen_step(h, B, sc, st);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != MGEA_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    MGEA_CHECK_HIP(e);
+    hipGraphExec_t ex = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        MGEA_CHECK_HIP(ei);
+    }
+    size_t nn = 0;
+    (void)hipGraphGetNodes(g, nullptr, &nn);
+    h->graphs.push_back({B, greedy, g, ex, (int64_t)nn, ++h->use_clock});
+    h->counters[0] = (int64_t)nn;
+    h->counters[2] += 1;   // lifetime captures + instantiations
+    h->counters[4] = (int64_t)h->graphs.size();
+    *out = ex;
+    return MGEA_OK;
 }
 
 int do_reset(mgea_decoder* h, int B, int max_len, hipStream_t st) {
@@ -570,12 +571,12 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     const bool cache_attn = (!post) && h->host_max_len > 0;
     if (fused_ok(h, (int)M)) {
         MGEA_TRY(launch_embed_stats(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, T, C, V,
-                                    c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, st));
+                                    c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
         MGEA_TRY(run_blocks_fused(h, main_bufs(h), B, T, lens, cache_attn, st));
     } else {
         MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                                  post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
-                                 V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, st));
+                                 V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
         MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
     }
     if (logits_out && fused_ok(h, (int)M)) {
@@ -673,9 +674,6 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
         h->no_gemv = gv && gv[0] == '1';
         const char* g = getenv("MGEA_DECODER_NOGRAPH");
         h->no_graph = g && g[0] == '1';
-        const char* ln = getenv("MGEA_DECODER_LANES");
-        h->n_lanes = ln ? atoi(ln) : 1;
-        if (h->n_lanes != 2 && h->n_lanes != 4) h->n_lanes = 1;
     }
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
@@ -698,7 +696,8 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     if (hipMalloc((void**)&h->page_table, nb * h->max_pages) != hipSuccess || hipMalloc((void**)&h->ctx_len, nb) != hipSuccess ||
         hipMalloc((void**)&h->cur_ids, nb) != hipSuccess || hipMalloc((void**)&h->done, nb) != hipSuccess ||
         hipMalloc((void**)&h->row_step, nb) != hipSuccess || hipMalloc((void**)&h->sampled, nb) != hipSuccess ||
-        hipMalloc((void**)&h->n_done, 16) != hipSuccess ||
+        hipMalloc((void**)&h->n_done, 16) != hipSuccess || hipMalloc((void**)&h->samp_dev, sizeof(SamplerParams)) != hipSuccess ||
+        hipMalloc((void**)&h->err_flag, 16) != hipSuccess ||
         hipMalloc((void**)&h->ids_hist, nb * h->ids_hist_stride) != hipSuccess)
         return fail(MGEA_ENOMEM, "state allocation failed");
     (void)hipMemset(h->page_table, 0, nb * h->max_pages);
@@ -707,25 +706,12 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     (void)hipMemset(h->row_step, 0, nb);
     (void)hipMemset(h->cur_ids, 0, nb);
     (void)hipMemset(h->n_done, 0, 16);
+    (void)hipMemset(h->samp_dev, 0, sizeof(SamplerParams));
+    (void)hipMemset(h->err_flag, 0, 16);
     const int rc = ensure_ws(h, cfg->max_batch > 64 ? cfg->max_batch : 64);
     if (rc != MGEA_OK) {
         mgea_decoder_destroy(h);
         return rc;
-    }
-    if (h->n_lanes > 1) {   // per-lane 64-row activation buffers (k-tiled), streams and join events
-        const int64_t C = cfg->d_model, F = cfg->d_ff, tiles = ceil_div(cfg->vocab, 16);
-        bool ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
-        for (int j = 0; j < h->n_lanes && ok; ++j) {
-            auto& L = h->lanes[j];
-            ok = hipMalloc((void**)&L.x, 64 * C * 4) == hipSuccess && hipMalloc((void**)&L.qkv, 64 * 3 * C * 4) == hipSuccess &&
-                 hipMalloc((void**)&L.att, 64 * C * 4) == hipSuccess && hipMalloc((void**)&L.hbuf, 64 * F * 4) == hipSuccess &&
-                 hipMalloc((void**)&L.stats, 64 * (C / 16 + 1) * 2 * 4) == hipSuccess &&
-                 hipMalloc((void**)&L.pmax_val, 64 * tiles * 4) == hipSuccess &&
-                 hipMalloc((void**)&L.pmax_idx, 64 * tiles * 4) == hipSuccess &&
-                 hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming) == hipSuccess;
-        }
-        if (!ok) return fail(MGEA_ENOMEM, "lane buffer allocation failed");
     }
     if (fused_geometry(*cfg)) {
         const int rc2 = build_tiled_weights(h, nullptr);
@@ -748,19 +734,12 @@ int mgea_decoder_refresh_weights(mgea_decoder* h, void* stream) {
 int mgea_decoder_destroy(mgea_decoder* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    drop_graph(h);
+    drop_graphs(h);
     free_ws(h);
-    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv};
+    void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv,
+                 h->samp_dev, h->err_flag};
     for (void* q : p)
         if (q) (void)hipFree(q);
-    for (auto& L : h->lanes) {
-        void* lp[] = {L.x, L.qkv, L.att, L.hbuf, L.stats, L.pmax_val, L.pmax_idx};
-        for (void* q : lp)
-            if (q) (void)hipFree(q);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
-        if (L.done_ev) (void)hipEventDestroy(L.done_ev);
-    }
-    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     delete h;
     return MGEA_OK;
 }
@@ -790,7 +769,7 @@ int mgea_decoder_step(mgea_decoder* h, const int32_t* ids_in_dev, const mgea_sam
     const int B = h->cur_batch;
     if (ids_in_dev)
         MGEA_CHECK_HIP(hipMemcpyAsync(h->cur_ids, ids_in_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    MGEA_TRY(enqueue_step(h, B, *s, logits_out_dev, st));
+    MGEA_TRY(enqueue_step(h, B, *s, nullptr, logits_out_dev, st));   // eager single step: the scalars travel by value
     h->host_max_len += 1;
     if (ids_out_dev)
         MGEA_CHECK_HIP(hipMemcpyAsync(ids_out_dev, h->sampled, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -812,27 +791,11 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
     MGEA_TRY(do_forward(h, prompt_ids_dev, lens_dev, B, Tp, nullptr, st));  // prefill, logits dropped (api_cache.py:163)
     if (n_steps == 0) return MGEA_OK;
 
-    // capture one decode step (all per-step state lives in device memory, so one graph serves every step)
-    if (!h->no_graph && (!h->gexec || h->g_batch != B || h->g_lanes != h->n_lanes || !same_sampler(h->g_samp, *s))) {
-        drop_graph(h);
-        MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_gen_step(h, B, *s, st);
-        hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(st, &g);
-        if (rc != MGEA_OK) {
-            if (g) (void)hipGraphDestroy(g);
-            return rc;
-        }
-        MGEA_CHECK_HIP(e);
-        h->graph = g;
-        MGEA_CHECK_HIP(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
-        h->g_batch = B;
-        h->g_lanes = h->n_lanes;
-        h->g_samp = *s;
-        size_t nn = 0;
-        (void)hipGraphGetNodes(g, nullptr, &nn);
-        h->counters[0] = (int64_t)nn;
-    }
+    // the request's sampler scalars -> device memory (stream-ordered), then the cached step graph of this batch size:
+    // all per-step state lives in device memory, so one graph serves every step of every request
+    MGEA_TRY(launch_set_sampler_params(h->samp_dev, *s, st));
+    hipGraphExec_t gexec = nullptr;
+    if (!h->no_graph) MGEA_TRY(step_graph(h, B, *s, st, &gexec));
     MGEA_TRY(prime_gen(h, B, st));   // x <- embedding of the re-fed last prompt token (api_cache.py:167)
     int launched = 0;
     int32_t host_done = 0;
@@ -845,7 +808,7 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
         } else if (h->no_graph) {
             MGEA_TRY(enqueue_gen_step(h, B, *s, st));
         } else {
-            MGEA_CHECK_HIP(hipGraphLaunch(h->gexec, st));
+            MGEA_CHECK_HIP(hipGraphLaunch(gexec, st));
         }
         ++launched;
         if (s->eos_id >= 0 && (i % 16) == 15) {  // stop once every row has drawn EOS (api_cache.py:181)
@@ -894,6 +857,18 @@ int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* lau
         (void)hipEventDestroy(r.b);
     }
     h->prof.clear();
+    return MGEA_OK;
+}
+
+int mgea_decoder_error_flags(mgea_decoder* h, int32_t* flags_out, void* stream) {
+    MGEA_REQUIRE(h && flags_out, MGEA_EINVAL, "decoder_error_flags: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t v = 0;
+    MGEA_CHECK_HIP(hipMemcpyAsync(&v, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MGEA_CHECK_HIP(hipStreamSynchronize(st));
+    if (v) MGEA_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
+    *flags_out = v;
     return MGEA_OK;
 }
 

@@ -482,13 +482,16 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restr
                                                          const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos_emb, float* __restrict__ x,
                                                          float* __restrict__ stats, int T, int C, int vocab,
-                                                         int pos_rows, int absolute_pos) {
+                                                         int pos_rows, int absolute_pos, int32_t* __restrict__ err_flag) {
     __shared__ float redv[4];
     const int64_t m = blockIdx.x;
     const int b = (int)(m / T), t = (int)(m % T);
     const int nf4 = C >> 2;
     const bool real = lens ? (t < lens[b]) : true;
     int id = ids[m];
+    // an id outside the vocabulary (nn.Embedding raises IndexError, api_cache.py:99) is clamped so that the loads stay in
+    // bounds and reported through the engine's sticky error flag (mgea_decoder_error_flags) -- no host sync per call
+    if (real && (id < 0 || id >= vocab) && err_flag && threadIdx.x == 0) atomicOr(err_flag, 1);
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     int pos = t + ((absolute_pos && ctx_len) ? ctx_len[b] : 0);
     pos = pos < pos_rows ? pos : pos_rows - 1;
@@ -528,11 +531,11 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const int32_t* __restr
 
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
-                       int absolute_pos, hipStream_t st) {
+                       int absolute_pos, int32_t* err_flag, hipStream_t st) {
     MGEA_REQUIRE(C % 4 == 0 && C <= 4096, MGEA_EINVAL, "embed: d_model=%d must be a multiple of 4 and <= 4096", C);
     MGEA_REQUIRE(B * T <= MGEA_FUSED_MAX_ROWS, MGEA_EINVAL, "embed (fused path): more than %d rows", MGEA_FUSED_MAX_ROWS);
     hipLaunchKernelGGL(embed_stats_kernel, dim3(B * T), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb, x, stats,
-                       T, C, vocab, pos_rows, absolute_pos);
+                       T, C, vocab, pos_rows, absolute_pos, err_flag);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(64) void argmax_advance_kernel(const float* __restr
             out = tok;
             s.cur_ids[b] = tok;
             s.ctx_len[b] += 1;
-            if (tok == s.eos_id) {
+            if (tok == s.eos()) {
                 s.done[b] = 1;
                 atomicAdd(s.n_done, 1);
             }

@@ -100,14 +100,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                       const float* __restrict__ pos_emb, float* __restrict__ x,
                                                       float* __restrict__ xn, const float* __restrict__ lnw,
                                                       const float* __restrict__ lnb, float eps, int T, int C, int vocab,
-                                                      int pos_rows, int absolute_pos) {
+                                                      int pos_rows, int absolute_pos, int32_t* __restrict__ err_flag) {
     __shared__ float red[4];
     const int64_t m = blockIdx.x;
     const int b = (int)(m / T), t = (int)(m % T);
     const int nf4 = C >> 2;
     const bool real = lens ? (t < lens[b]) : true;
     int id = ids[m];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // host validates ids; clamp keeps loads in bounds
+    if (real && (id < 0 || id >= vocab) && err_flag && threadIdx.x == 0) atomicOr(err_flag, 1);   // see embed_stats_kernel
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // clamp keeps the loads in bounds
     int pos = t + ((absolute_pos && ctx_len) ? ctx_len[b] : 0);
     pos = pos < pos_rows ? pos : pos_rows - 1;
     RowRegs r;
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
 
 int launch_embed_ln(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                     const float* pos_emb, float* x, float* xn, const float* lnw, const float* lnb, float eps,
-                    int B, int T, int C, int vocab, int pos_rows, int absolute_pos, hipStream_t st) {
+                    int B, int T, int C, int vocab, int pos_rows, int absolute_pos, int32_t* err_flag, hipStream_t st) {
     MGEA_REQUIRE(C % 4 == 0 && C <= 4096, MGEA_EINVAL, "embed: d_model=%d must be a multiple of 4 and <= 4096", C);
     hipLaunchKernelGGL(embed_ln_kernel, dim3(B * T), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb, x, xn,
-                       lnw, lnb, eps, T, C, vocab, pos_rows, absolute_pos);
+                       lnw, lnb, eps, T, C, vocab, pos_rows, absolute_pos, err_flag);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -362,7 +363,7 @@ __global__ void advance_kernel(const int32_t* __restrict__ sampled, StepState s,
         out = tok;
         s.cur_ids[b] = tok;
         s.ctx_len[b] += 1;  // the token fed this step now sits in the cache
-        if (tok == s.eos_id) {
+        if (tok == s.eos()) {
             s.done[b] = 1;
             atomicAdd(s.n_done, 1);
         }

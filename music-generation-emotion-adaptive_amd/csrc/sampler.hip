@@ -4,8 +4,11 @@
 //
 // One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted:
 //   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys held in
-//             registers (integer counts -> deterministic); kept = {logit >= k-th}.  exp(-1e10)
-//             underflows to exactly 0 in fp32, so "mask then softmax" == "softmax over kept".
+//             registers (integer counts -> deterministic); kept = {logit > k-th} plus as many of the
+//             entries EQUAL to the k-th as it takes to keep exactly k, lowest ids first (topk + scatter_ of
+//             api_cache.py:172-175 keeps exactly top_k entries; which of several tied ones torch keeps is
+//             unspecified, lowest-id is this build's rule).  exp(-1e10) underflows to exactly 0 in fp32, so
+//             "mask then softmax" == "softmax over kept".
 //   * top-p : the nucleus {i : mass of strictly larger logits < top_p} by the same bisection over
 //             fixed-point (2^-40) probability masses (64-bit integer sums -> deterministic);
 //             kept = {logit >= boundary}.
@@ -14,6 +17,9 @@
 //             stream cannot be reproduced on device: equality with the reference is
 //             distributional, the pre-draw probabilities are compared exactly (probs_out).
 // top_k == 1 is the argmax path (rowops.hip, ties to the lowest id) for the ids.
+// The sampler's scalars (temperature, top_k, top_p, seed; eos for the fused tail) are read from a SamplerParams
+// record in DEVICE memory when the caller passes one: the captured decode graph then serves every request, whatever
+// its seed (the reference's endpoint draws a fresh one per call, api_cache.py:204).
 #include "common.h"
 
 namespace mgea {
@@ -64,9 +70,11 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // bytes its 64-bit LDS atomics serialised.)
 template <bool MASS, int MAXE>
 __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE], const uint32_t (&whi)[MAXE], const uint32_t (&wlo)[MAXE],
-                                                    uint32_t floor_key, unsigned long long target, unsigned long long* red /* [8] */) {
+                                                    uint32_t floor_key, unsigned long long target, unsigned long long* red /* [8] */,
+                                                    unsigned long long* weight_at_boundary = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t prefix = 0u;
+    unsigned long long at = ~0ull;   // weight({key >= prefix}): everything while prefix == 0
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit);
         const uint32_t lim = cand > floor_key ? cand : floor_key;   // only keys >= floor_key are candidates
@@ -89,21 +97,28 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
         unsigned long long* slot = red + 4 * (bit & 1);
         if (lane == 0) slot[wave] = mine;
         __syncthreads();
-        if ((slot[0] + slot[1]) + (slot[2] + slot[3]) >= target) prefix = cand;
+        const unsigned long long tot = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+        if (tot >= target) { prefix = cand; at = tot; }
     }
     __syncthreads();   // the slots are reused by the caller
+    if (weight_at_boundary) *weight_at_boundary = at;
     return prefix > floor_key ? prefix : floor_key;
 }
 
 // One 256-thread workgroup per row; thread t owns the logits t, t + 256, ... in registers (MAXE of them), so the row is
 // read from memory once, in one batch of loads, and never goes through LDS.
 template <int MAXE>
-__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int V, float temperature,
-                                                    int top_k, float top_p, uint64_t seed,
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int V, SamplerParams pv,
+                                                    const SamplerParams* __restrict__ pd,
                                                     const int32_t* __restrict__ row_step, int64_t step_host,
                                                     int32_t* __restrict__ ids_out, float* __restrict__ probs_out,
                                                     TailArgs tail, int fuse_tail) {
     __shared__ unsigned long long red64[8];
+    __shared__ int s_tie[4];
+    if (pd) pv = *pd;   // device-resident scalars (one 32-byte scalar load) win over the by-value copy
+    const float temperature = pv.temperature, top_p = pv.top_p;
+    const int top_k = pv.top_k;
+    const uint64_t seed = ((uint64_t)pv.seed_hi << 32) | pv.seed_lo;
     __shared__ float redf[4];
     __shared__ float s_scan[4];
     __shared__ int s_thread, s_choice;
@@ -142,7 +157,36 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         whi[j] = wlo[j] = 0u;
     }
     uint32_t keep_key = 0u;  // keep everything
-    if (top_k > 0 && top_k < V) keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64);
+    if (top_k > 0 && top_k < V) {
+        unsigned long long n_ge = 0;
+        keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64, &n_ge);
+        if (n_ge > (unsigned long long)top_k) {
+            // several logits equal the k-th largest: keep exactly top_k entries, the tied ones by ascending id
+            // (id = tid + 256 j, so the order is j-major, thread-minor).  Rare (exact fp32 ties): block-uniform branch.
+            uint32_t n_gt = 0u;
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) n_gt += (uint32_t)__popcll(__ballot(key[j] > keep_key));
+            if ((tid & 63) == 0) s_tie[tid >> 6] = (int)n_gt;
+            __syncthreads();
+            const int need = top_k - ((s_tie[0] + s_tie[1]) + (s_tie[2] + s_tie[3]));   // >= 1 tied entries survive
+            __syncthreads();
+            int seen = 0;   // tied entries with a lower id than this pass's (block-uniform)
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) {
+                const bool tie = key[j] == keep_key;
+                const unsigned long long bal = __ballot(tie);
+                if ((tid & 63) == 0) s_tie[tid >> 6] = __popcll(bal);
+                __syncthreads();
+                int before = seen + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                for (int w = 0; w < 4; ++w) {
+                    if (w < (tid >> 6)) before += s_tie[w];
+                    seen += s_tie[w];
+                }
+                if (tie && before >= need) key[j] = 0u;   // 0 = not a candidate: below every kept key
+                __syncthreads();
+            }
+        }
+    }
     if (top_p > 0.f && top_p < 1.f) {
         float z = 0.f;
 #pragma unroll
@@ -221,18 +265,29 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     else if (tid == 0) ids_out[b] = tok;
 }
 
-int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const int32_t* row_step_dev,
-                  int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st, const TailArgs* tail) {
-    MGEA_REQUIRE(s.temperature > 0.f, MGEA_EINVAL, "sampler: temperature must be > 0");
-    MGEA_REQUIRE(V > 0 && V <= 14336, MGEA_EINVAL, "sampler: vocab %d exceeds the register-resident row (14336)", V);
+int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& s, const SamplerParams* params_dev,
+                  const int32_t* row_step_dev, int64_t step_host, int32_t* ids_out, float* probs_out, hipStream_t st, const TailArgs* tail) {
+    MGEA_REQUIRE(params_dev || s.temperature > 0.f, MGEA_EINVAL, "sampler: temperature must be > 0");
+    MGEA_REQUIRE(V > 0 && V <= MGEA_SAMPLER_MAX_VOCAB, MGEA_EINVAL, "sampler: vocab %d exceeds the register-resident row (%d)", V,
+                 MGEA_SAMPLER_MAX_VOCAB);
     MGEA_REQUIRE(!tail || (ids_out && tail->C % 4 == 0 && tail->C <= 4096), MGEA_EINVAL, "sampler: bad fused-tail arguments");
     const TailArgs t = tail ? *tail : TailArgs{};
+    const SamplerParams pv = sampler_params(s);
     if (V <= 256 * 36)
-        hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(256), 0, st, logits, V, s.temperature, s.top_k, s.top_p, (uint64_t)s.seed,
-                           row_step_dev, step_host, ids_out, probs_out, t, tail ? 1 : 0);
+        hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(256), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
+                           probs_out, t, tail ? 1 : 0);
     else
-        hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(256), 0, st, logits, V, s.temperature, s.top_k, s.top_p, (uint64_t)s.seed,
-                           row_step_dev, step_host, ids_out, probs_out, t, tail ? 1 : 0);
+        hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(256), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
+                           probs_out, t, tail ? 1 : 0);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// params_dev <- s, stream-ordered (a kernel argument, so no host buffer has to outlive the call)
+__global__ void set_sampler_params_kernel(SamplerParams* dst, SamplerParams v) { *dst = v; }
+
+int launch_set_sampler_params(SamplerParams* params_dev, const mgea_sampler_config& s, hipStream_t st) {
+    hipLaunchKernelGGL(set_sampler_params_kernel, dim3(1), dim3(1), 0, st, params_dev, sampler_params(s));
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -5,10 +5,12 @@ directory in Hugging Face layout, read with loaders that execute nothing from th
     vocab.txt                      WordPiece vocabulary
     model.safetensors | pytorch_model.bin          DistilBertForSequenceClassification weights
     adapter_model.safetensors | adapter_model.bin  peft LoRA tensors (+ modules_to_save heads), optional
-    adapter_config.json            r / lora_alpha, optional (defaults r=8, alpha=16)
+    adapter_config.json            r / lora_alpha / use_rslora / rank_pattern / alpha_pattern, optional
+                                   (defaults r = rank of the tensors, alpha = 16)
     config.json                    n_heads (default 12)
-The LoRA branch is folded into the weights on the device (W' = W + alpha/r B A) and the forward
-runs in libmgea_hip.so."""
+Every LoRA pair of the adapter, whatever Linear it targets, is folded into the weights on the device
+(W' = W + scale B A, mgea.bert.resolve_adapter); adapter tensors the loader cannot apply raise instead
+of being dropped.  The forward runs in libmgea_hip.so."""
 import json
 import os
 from typing import Dict, Optional
@@ -43,14 +45,15 @@ def load_model(model_dir: Optional[str] = None, device: str = "cuda:0", max_toke
     if sd is None:
         raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {model_dir}")
     ad = _load_tensors(j("adapter_model.safetensors"), j("adapter_model.bin"))
-    n_heads, alpha, r = 12, 16.0, None
+    n_heads, ac = 12, None
     if os.path.exists(j("config.json")):
-        n_heads = int(json.load(open(j("config.json"))).get("n_heads", 12))
+        with open(j("config.json")) as f:
+            n_heads = int(json.load(f).get("n_heads", 12))
     if os.path.exists(j("adapter_config.json")):
-        ac = json.load(open(j("adapter_config.json")))
-        alpha, r = float(ac.get("lora_alpha", 16)), ac.get("r")
+        with open(j("adapter_config.json")) as f:
+            ac = json.load(f)
     if int(sd["classifier.weight"].shape[0]) != NUM_LABELS and not ad:
         raise RuntimeError(f"classifier has {sd['classifier.weight'].shape[0]} labels, expected {NUM_LABELS}")
     tokenizer = WordPieceTokenizer(j("vocab.txt"))
-    engine = BertEngine(sd, n_heads=n_heads, adapter=ad, lora_alpha=alpha, lora_r=r, max_tokens=max_tokens, device=device)
+    engine = BertEngine(sd, n_heads=n_heads, adapter=ad, adapter_config=ac, max_tokens=max_tokens, device=device)
     return tokenizer, engine

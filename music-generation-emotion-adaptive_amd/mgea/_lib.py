@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgea_hip.so")
 
 OK, EINVAL, ENOMEM, EHIP, ECAPACITY, ENODEVICE = 0, -1, -2, -3, -4, -5
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 BLOCK_PRELN_GELU, BLOCK_POSTLN_RELU = 0, 1
 POS_REFERENCE, POS_ABSOLUTE = 0, 1
 KV_PAGE_TOKENS = 64
@@ -57,6 +57,7 @@ PROTOTYPES = {
     "mgea_decoder_generate": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, C.POINTER(SamplerConfig), _P, _P]),
     "mgea_decoder_context_lengths": (C.c_int, [_P, _P, _P]),
     "mgea_decoder_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "mgea_decoder_error_flags": (C.c_int, [_P, C.POINTER(_I32), _P]),
     "mgea_decoder_profile": (C.c_int, [_P, _I32]),
     "mgea_decoder_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "mgea_bert_arena_layout": (C.c_int, [C.POINTER(BertConfig), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),

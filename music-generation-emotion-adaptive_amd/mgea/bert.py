@@ -3,7 +3,9 @@ call of emotion_analysis/inference.py:16-20).  Torch = device memory + streams o
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+import math
+import re
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -27,11 +29,86 @@ def geometry_from_state_dict(sd: Dict) -> Dict[str, int]:
                 num_labels=int(sd["classifier.weight"].shape[0]))
 
 
+_LORA_KEY = re.compile(r"^(?P<mod>.+)\.lora_(?P<ab>[AB])(?:\.[^.]+)?\.weight$")
+
+
+def _base_name(key: str) -> str:
+    """peft tensor name -> name in the base model's state dict: `base_model.model.` prefix,
+    `.modules_to_save.<adapter>` / `.base_layer` wrappers removed."""
+    k = key[len("base_model.model."):] if key.startswith("base_model.model.") else key
+    k = re.sub(r"\.modules_to_save(\.[^.]+)?(?=\.(weight|bias)$)", "", k)
+    return k.replace(".base_layer.", ".")
+
+
+def _pattern_value(pattern: Optional[Dict], module: str, default):
+    """peft's rank_pattern / alpha_pattern lookup: the first key that is the module name or a suffix of it
+    (regex allowed) wins."""
+    for key, val in (pattern or {}).items():
+        if re.match(rf"(.*\.)?{key}$", module):
+            return val
+    return default
+
+
+def resolve_adapter(sd: Dict, adapter: Optional[Dict], adapter_config: Optional[Dict] = None, lora_alpha: float = 16.0,
+                    lora_r: Optional[int] = None) -> Tuple[Dict, Dict]:
+    """Turn a peft adapter (what PeftModel.from_pretrained applies, emotion_analysis/modeling.py:14-21) into
+    (overrides, loras): `overrides[base_key]` replaces a base tensor (modules_to_save heads, trained biases) and
+    `loras[module] = (A [r, in], B [out, r], scale)` is folded as W' = W + scale * B @ A for EVERY Linear the adapter
+    targets (q_lin / k_lin / v_lin / out_lin / ffn.lin1 / ffn.lin2 / pre_classifier / classifier).  scale follows
+    peft: lora_alpha / r, or lora_alpha / sqrt(r) with use_rslora, with rank_pattern / alpha_pattern per module.
+    Anything in the adapter that is not consumed (DoRA magnitudes, embedding LoRA, unknown names) raises: a dropped
+    tensor would silently change the logits.  peft is not importable here, so this is restated from its published
+    definition (parity unpinned; merged == unmerged is what the tests can check)."""
+    cfg = dict(adapter_config or {})
+    if cfg.get("use_dora"):
+        raise NotImplementedError("adapter_config.use_dora: DoRA adapters are not supported")
+    if cfg.get("fan_in_fan_out"):
+        raise NotImplementedError("adapter_config.fan_in_fan_out: transposed base weights are not supported")
+    alpha0 = float(cfg.get("lora_alpha", lora_alpha))
+    r0 = cfg.get("r", lora_r)
+    overrides: Dict = {}
+    halves: Dict[str, Dict[str, object]] = {}
+    leftover: List[str] = []
+    for key, t in (adapter or {}).items():
+        if ".original_module." in key:      # peft keeps the frozen copy of a modules_to_save layer beside the trained one
+            continue
+        name = _base_name(key)
+        m = _LORA_KEY.match(name)
+        if m:
+            halves.setdefault(m.group("mod"), {})[m.group("ab")] = t
+        elif name in sd:
+            if tuple(t.shape) != tuple(sd[name].shape):
+                raise ValueError(f"adapter tensor {key} has shape {tuple(t.shape)}, the base model's {name} has {tuple(sd[name].shape)}")
+            overrides[name] = t
+        else:
+            leftover.append(key)
+    loras: Dict = {}
+    for mod, ab in halves.items():
+        wkey = mod + ".weight"
+        if "A" not in ab or "B" not in ab or wkey not in sd or len(sd[wkey].shape) != 2:
+            leftover += [k for k in adapter if _base_name(k).startswith(mod + ".lora_")]
+            continue
+        A, Bm = ab["A"], ab["B"]
+        out_dim, in_dim = (int(x) for x in sd[wkey].shape)
+        r = int(A.shape[0])
+        if tuple(A.shape) != (r, in_dim) or tuple(Bm.shape) != (out_dim, r):
+            raise ValueError(f"LoRA shapes of {mod}: A {tuple(A.shape)} B {tuple(Bm.shape)} do not fit W [{out_dim}, {in_dim}]")
+        r_cfg = _pattern_value(cfg.get("rank_pattern"), mod, r0)
+        if r_cfg is not None and int(r_cfg) != r:
+            raise ValueError(f"LoRA rank of {mod} is {r}, adapter_config says {r_cfg}")
+        alpha = float(_pattern_value(cfg.get("alpha_pattern"), mod, alpha0))
+        loras[mod] = (A, Bm, alpha / math.sqrt(r) if cfg.get("use_rslora") else alpha / r)
+    if leftover:
+        raise ValueError(f"adapter tensors that this loader cannot apply (they would be dropped silently): {sorted(leftover)[:6]}"
+                         f"{' ...' if len(leftover) > 6 else ''}")
+    return overrides, loras
+
+
 class BertEngine:
     def __init__(self, state_dict: Optional[Dict], n_heads: int = 12, adapter: Optional[Dict] = None,
                  lora_alpha: float = 16.0, lora_r: Optional[int] = None, max_tokens: int = 256 * 128,
                  device="cuda:0", geometry: Optional[Dict] = None, arena: Optional[torch.Tensor] = None,
-                 ln_eps: float = 1e-12, dtype: str = "f32"):
+                 ln_eps: float = 1e-12, dtype: str = "f32", adapter_config: Optional[Dict] = None):
         """dtype "f32" = parity mode (exact-fp32 MFMA); "bf16" = perf mode (bf16 weights/activations,
         fp32 accumulate, fp32 LayerNorm/softmax/GELU; the arena stays fp32 and is converted once)."""
         self.lib = _lib.load()
@@ -59,20 +136,22 @@ class BertEngine:
                 raise ValueError("arena tensor has the wrong size / dtype / device")
             self.arena = arena
         else:
-            self.arena = self.pack_arena(state_dict, adapter, lora_alpha, lora_r)
+            self.arena = self.pack_arena(state_dict, adapter, lora_alpha, lora_r, adapter_config)
         torch.cuda.synchronize(self.device)
         h = C.c_void_p(0)
         check(self.lib.mgea_bert_create(C.byref(self.cfg), ptr(self.arena), C.byref(h)))
         self.h = h
 
-    def pack_arena(self, sd, adapter, lora_alpha, lora_r) -> torch.Tensor:
-        """Canonical arena of mgea.h.  q_lin/k_lin/v_lin are stacked into one [3D, D] matrix; LoRA
-        A/B (peft names `base_model.model.<...>.lora_A.weight`, optionally `.default.`) are folded
-        in place on the device by mgea_lora_merge: W' = W + (alpha/r) B A."""
+    def pack_arena(self, sd, adapter, lora_alpha, lora_r, adapter_config=None) -> torch.Tensor:
+        """Canonical arena of mgea.h.  q_lin/k_lin/v_lin are stacked into one [3D, D] matrix; every LoRA pair of
+        the adapter (resolve_adapter) is folded in place on the device by mgea_lora_merge: W' = W + scale * B A."""
         geo, dev = self.geo, self.device
-        D = geo["dim"]
+        D, Hd = geo["dim"], geo["hidden"]
+        overrides, loras = resolve_adapter(sd, adapter, adapter_config, lora_alpha, lora_r)
+        sd = {**sd, **overrides}      # modules_to_save heads / trained biases replace the base tensors
         arena = torch.zeros(self.arena_floats, dtype=torch.float32, device=dev)
         it = iter(self.offsets)
+        slot = {}                      # Linear module -> (arena offset of its weight, out_dim, in_dim)
 
         def put(t):
             off = next(it)
@@ -83,49 +162,34 @@ class BertEngine:
         e = "distilbert.embeddings."
         put(sd[e + "word_embeddings.weight"]); put(sd[e + "position_embeddings.weight"])
         put(sd[e + "LayerNorm.weight"]); put(sd[e + "LayerNorm.bias"])
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        keep = []
         for i in range(geo["n_layers"]):
             p = f"distilbert.transformer.layer.{i}."
             qkv_w = torch.cat([_f32(sd[p + f"attention.{nm}.weight"], dev) for nm in ("q_lin", "k_lin", "v_lin")], 0)
             qkv_b = torch.cat([_f32(sd[p + f"attention.{nm}.bias"], dev) for nm in ("q_lin", "k_lin", "v_lin")], 0)
             off = put(qkv_w)
             put(qkv_b)
-            if adapter:
-                for j, nm in enumerate(("q_lin", "k_lin", "v_lin")):
-                    A = self._find(adapter, f"transformer.layer.{i}.attention.{nm}.lora_A")
-                    Bm = self._find(adapter, f"transformer.layer.{i}.attention.{nm}.lora_B")
-                    if A is None or Bm is None:
-                        continue
-                    A, Bm = _f32(A, dev), _f32(Bm, dev)
-                    r = A.shape[0]
-                    keep += [A, Bm]
-                    scale = float(lora_alpha) / float(lora_r or r)
-                    w_ptr = C.c_void_p(arena.data_ptr() + 4 * (off + j * D * D))
-                    check(self.lib.mgea_lora_merge(w_ptr, ptr(A), ptr(Bm), D, D, r, scale, stream))
-            put(sd[p + "attention.out_lin.weight"]); put(sd[p + "attention.out_lin.bias"])
+            for j, nm in enumerate(("q_lin", "k_lin", "v_lin")):
+                slot[p + f"attention.{nm}"] = (off + j * D * D, D, D)
+            slot[p + "attention.out_lin"] = (put(sd[p + "attention.out_lin.weight"]), D, D); put(sd[p + "attention.out_lin.bias"])
             put(sd[p + "sa_layer_norm.weight"]); put(sd[p + "sa_layer_norm.bias"])
-            put(sd[p + "ffn.lin1.weight"]); put(sd[p + "ffn.lin1.bias"])
-            put(sd[p + "ffn.lin2.weight"]); put(sd[p + "ffn.lin2.bias"])
+            slot[p + "ffn.lin1"] = (put(sd[p + "ffn.lin1.weight"]), Hd, D); put(sd[p + "ffn.lin1.bias"])
+            slot[p + "ffn.lin2"] = (put(sd[p + "ffn.lin2.weight"]), D, Hd); put(sd[p + "ffn.lin2.bias"])
             put(sd[p + "output_layer_norm.weight"]); put(sd[p + "output_layer_norm.bias"])
-        # peft `modules_to_save` heads override the base ones when present in the adapter
-        for nm in ("pre_classifier", "classifier"):
-            for part in ("weight", "bias"):
-                t = self._find(adapter, f"model.{nm}.", part) if adapter else None
-                put(t if t is not None else sd[f"{nm}.{part}"])
+        slot["pre_classifier"] = (put(sd["pre_classifier.weight"]), D, D); put(sd["pre_classifier.bias"])
+        slot["classifier"] = (put(sd["classifier.weight"]), geo["num_labels"], D); put(sd["classifier.bias"])
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        keep = []
+        for mod, (A, Bm, scale) in loras.items():
+            if mod not in slot:
+                raise ValueError(f"LoRA target {mod} is not a Linear of the classifier")
+            off, out_dim, in_dim = slot[mod]
+            A, Bm = _f32(A, dev), _f32(Bm, dev)
+            keep += [A, Bm]
+            w_ptr = C.c_void_p(arena.data_ptr() + 4 * off)
+            check(self.lib.mgea_lora_merge(w_ptr, ptr(A), ptr(Bm), out_dim, in_dim, int(A.shape[0]), float(scale), stream))
         torch.cuda.synchronize(dev)
         del keep
         return arena
-
-    @staticmethod
-    def _find(adapter, frag, suffix="weight"):
-        """First adapter tensor whose name contains `frag` and ends with `suffix` (peft writes
-        `...q_lin.lora_A.weight` to disk and `...q_lin.lora_A.default.weight` in memory; saved heads
-        are `base_model.model.pre_classifier[.modules_to_save.default].weight`)."""
-        for k, v in adapter.items():
-            if frag in k and k.endswith(suffix):
-                return v
-        return None
 
     def close(self):
         if getattr(self, "h", None):

@@ -167,9 +167,26 @@ class DecoderEngine:
     def _sp(self):
         return C.c_void_p(self.stream.cuda_stream)
 
-    def _check_ids(self, ids: torch.Tensor):
+    def _check_ids(self, ids: torch.Tensor) -> bool:
+        """Token ids outside the vocabulary: nn.Embedding raises IndexError in the reference (api_cache.py:99).
+        A HOST tensor is checked here, before the upload, at no GPU cost.  A DEVICE tensor is not read back (that
+        would put a host sync in front of every call of the reference's own loop, api_cache.py:166-168): the
+        kernels clamp such ids and set a sticky device flag, see id_errors().  Returns True if it checked."""
+        if ids.is_cuda:
+            return False
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.vocab):
             raise IndexError("index out of range in self")  # what nn.Embedding raises on CPU
+        return True
+
+    def id_errors(self, raise_error: bool = True) -> int:
+        """Read and clear the engine's sticky device flags (ONE stream sync): bit 0 = some token id handed over as a
+        device tensor since the last call was outside the vocabulary (and was clamped)."""
+        flags = C.c_int32(0)
+        with self._on_stream():
+            check(self.lib.mgea_decoder_error_flags(self.h, C.byref(flags), self._sp()))
+        if raise_error and (flags.value & 1):
+            raise IndexError("index out of range in self")
+        return flags.value
 
     @staticmethod
     def sampler(temperature=1.0, top_k: Optional[int] = 50, top_p: Optional[float] = None, eos_id: int = -1,
@@ -220,9 +237,12 @@ class DecoderEngine:
 
     # ------------------------------------------------------------------ sample_kvcache surface
     def generate(self, prompts, n_steps: int, temperature: float = 1.0, top_k: Optional[int] = 50,
-                 top_p: Optional[float] = None, eos_id: int = -1, seed: int = 0) -> torch.Tensor:
+                 top_p: Optional[float] = None, eos_id: int = -1, seed: int = 0, check_ids: bool = True) -> torch.Tensor:
         """Batched sample_kvcache (api_cache.py:159-184).  prompts: list of id lists (ragged ok) or
-        an int tensor [B, Tp].  Returns int32 [B, n_steps] of generated ids (-1 after a row's EOS)."""
+        an int tensor [B, Tp].  Returns int32 [B, n_steps] of generated ids (-1 after a row's EOS).
+        check_ids: prompts given as a DEVICE tensor are range-checked through the device flag once the
+        generation has been enqueued (one sync at the end, which the caller's read of the ids needs anyway);
+        False skips even that and leaves the flag for id_errors()."""
         if isinstance(prompts, torch.Tensor):
             ids = prompts.to(torch.int32)
             lens = None
@@ -236,7 +256,7 @@ class DecoderEngine:
                 ids[b, :len(p)] = torch.tensor(list(p), dtype=torch.int32)
             lens = None if all(len(p) == Tp for p in prompts) else torch.tensor([len(p) for p in prompts], dtype=torch.int32)
         B, Tp = ids.shape
-        self._check_ids(ids)
+        checked = self._check_ids(ids)
         samp = self.sampler(temperature, top_k, top_p, eos_id, seed)
         with self._on_stream():
             ids = ids.to(self.device).contiguous()
@@ -246,6 +266,8 @@ class DecoderEngine:
                                                  self._sp()))
         self._cur_batch = B
         self._epoch += 1
+        if check_ids and not checked:
+            self.id_errors()
         return out[:, :n_steps]
 
     def reset_and_prefill(self, idx: torch.Tensor, lens=None, want_logits=True, max_len=None):
@@ -267,4 +289,4 @@ class DecoderEngine:
     def stats(self):
         out = (C.c_int64 * 8)()
         check(self.lib.mgea_decoder_stats(self.h, out))
-        return dict(graph_nodes=out[0], graph_replays=out[1])
+        return dict(graph_nodes=out[0], graph_replays=out[1], graph_instantiates=out[2], graphs_cached=out[4])

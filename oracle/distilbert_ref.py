@@ -9,7 +9,7 @@ reached through emotion_analysis/modeling.py:14-21.  Restated here from the publ
 definition (transformers modeling_distilbert.py: Embeddings, MultiHeadSelfAttention, FFN,
 TransformerBlock, DistilBertForSequenceClassification) and the LoRA definition
 y = W x + b + (alpha/r) B (A x) (r=8, alpha=16, targets q_lin/v_lin:
-Scripts/finetuneDistillBert.ipynb:787-795).  Pinned against logits produced by the container's
+Scripts/finetuneDistillBert.ipynb:787-795; any other Linear target is handled the same way).  Pinned against logits produced by the container's
 local `transformers` class on the same synthetic weights (tests/golden/distilbert_*.npz); the
 LoRA branch itself is parity-unpinned (peft absent) beyond merged == unmerged equality.
 
@@ -37,31 +37,42 @@ def _t(a) -> torch.Tensor:
 class DistilBertRef:
     def __init__(self, state_dict: Dict, n_heads: int, adapter: Optional[Dict] = None,
                  lora_scale: float = 2.0, merge: bool = True):
+        """adapter: peft-named tensors `base_model.model.<module>.lora_A.weight` [r, in] / `.lora_B.weight` [out, r]
+        on ANY Linear of the model (the reference's adapter targets q_lin / v_lin; peft applies whatever the adapter
+        holds) plus optional `base_model.model.<name>` tensors that replace base ones (modules_to_save heads).
+        merge=True folds W' = W + lora_scale * B @ A; merge=False keeps the LoRA branch y += lora_scale * B (A x)."""
         self.sd = {k: _t(v) for k, v in state_dict.items()}
-        self.ad = {k: _t(v) for k, v in (adapter or {}).items()}
+        self.ad = {}
+        for k, v in (adapter or {}).items():
+            name = k[len("base_model.model."):] if k.startswith("base_model.model.") else k
+            if ".lora_" in name:
+                self.ad[name] = _t(v)
+            else:
+                self.sd[name] = _t(v)
         self.H = n_heads
         self.scale = lora_scale
         self.D = self.sd["distilbert.embeddings.word_embeddings.weight"].shape[1]
         self.L = 1 + max(int(k.split(".")[3]) for k in self.sd if k.startswith("distilbert.transformer.layer."))
         self.merge = merge
-        if merge and self.ad:
-            for i in range(self.L):
-                for nm in ("q_lin", "v_lin"):
-                    A, B = self._lora(i, nm)
-                    k = f"distilbert.transformer.layer.{i}.attention.{nm}.weight"
-                    self.sd[k] = self.sd[k] + self.scale * (B @ A)
+        if merge:
+            for mod in sorted({k.split(".lora_")[0] for k in self.ad}):
+                A, B = self._lora(mod)
+                self.sd[mod + ".weight"] = self.sd[mod + ".weight"] + self.scale * (B @ A)
 
-    def _lora(self, i, nm):
-        p = f"base_model.model.distilbert.transformer.layer.{i}.attention.{nm}."
-        return self.ad[p + "lora_A.weight"], self.ad[p + "lora_B.weight"]
+    def _lora(self, mod):
+        if mod + ".lora_A.weight" not in self.ad:
+            return None
+        return self.ad[mod + ".lora_A.weight"], self.ad[mod + ".lora_B.weight"]
+
+    def _linear(self, x, mod):
+        y = x @ self.sd[mod + ".weight"].t() + self.sd[mod + ".bias"]
+        ab = None if self.merge else self._lora(mod)
+        if ab is not None:
+            y = y + self.scale * ((x @ ab[0].t()) @ ab[1].t())
+        return y
 
     def _lin(self, x, i, nm):
-        p = f"distilbert.transformer.layer.{i}.attention.{nm}."
-        y = x @ self.sd[p + "weight"].t() + self.sd[p + "bias"]
-        if (not self.merge) and self.ad and nm in ("q_lin", "v_lin"):
-            A, B = self._lora(i, nm)
-            y = y + self.scale * ((x @ A.t()) @ B.t())
-        return y
+        return self._linear(x, f"distilbert.transformer.layer.{i}.attention.{nm}")
 
     @torch.no_grad()
     def forward(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -87,8 +98,8 @@ class DistilBertRef:
             a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, D)
             a = self._lin(a, i, "out_lin")
             h = F.layer_norm(a + h, (D,), sd[p + "sa_layer_norm.weight"], sd[p + "sa_layer_norm.bias"], 1e-12)
-            f = F.gelu(h @ sd[p + "ffn.lin1.weight"].t() + sd[p + "ffn.lin1.bias"])
-            f = f @ sd[p + "ffn.lin2.weight"].t() + sd[p + "ffn.lin2.bias"]
+            f = F.gelu(self._linear(h, p + "ffn.lin1"))
+            f = self._linear(f, p + "ffn.lin2")
             h = F.layer_norm(f + h, (D,), sd[p + "output_layer_norm.weight"], sd[p + "output_layer_norm.bias"], 1e-12)
-        pooled = torch.relu(h[:, 0] @ sd["pre_classifier.weight"].t() + sd["pre_classifier.bias"])
-        return pooled @ sd["classifier.weight"].t() + sd["classifier.bias"]
+        pooled = torch.relu(self._linear(h[:, 0], "pre_classifier"))
+        return self._linear(pooled, "classifier")

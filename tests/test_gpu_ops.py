@@ -95,6 +95,33 @@ def test_sampler_probabilities_match_reference_restatement(ops):
             assert ids.cpu().tolist() == logits.argmax(1).tolist()
 
 
+def test_topk_keeps_exactly_k_on_ties(ops):
+    """api_cache.py:172-175: topk + scatter_ leaves exactly top_k entries unmasked, also when several logits equal the
+    k-th largest.  Which of the tied entries torch keeps is unspecified; here it is the lowest ids."""
+    V, k = 700, 50
+    flat = torch.zeros(1, V)                                            # everything tied
+    lg = torch.full((1, V), -1.0)
+    lg[0, torch.arange(5, 700, 70)] = 3.0                               # 10 clear winners ...
+    lg[0, 300:420] = 1.5                                                # ... then 120 entries tied for places 11..130
+    rnd = torch.randn(1, V)
+    rnd[0, 100] = rnd[0, 613] = rnd[0, 7] = float(rnd.topk(k).values[0, -1])   # three-way tie exactly at the boundary
+    for logits in (flat, lg, rnd):
+        _, probs = ops.sample(logits.cuda(), 1.0, k, None, seed=1, step=0, want_probs=True)
+        p = probs.cpu()[0]
+        kept = (p > 0).nonzero().flatten().tolist()
+        assert len(kept) == k, f"{len(kept)} entries survive a top-{k} cut"
+        assert abs(float(p.sum()) - 1.0) < 1e-5
+        kth = float(logits[0].topk(k).values[-1])
+        above = (logits[0] > kth).nonzero().flatten().tolist()
+        tied = (logits[0] == kth).nonzero().flatten().tolist()
+        assert kept == sorted(above + tied[: k - len(above)])           # all larger ones, then ties by ascending id
+        want = torch.softmax(logits[0][kept].double(), 0)
+        np.testing.assert_allclose(p[kept].double().numpy(), want.numpy(), atol=1e-6)
+    # top-p after such a cut still works on the k survivors
+    _, probs = ops.sample(lg.cuda(), 1.0, k, 0.5, seed=1, step=0, want_probs=True)
+    assert 1 <= int((probs > 0).sum()) <= k
+
+
 def test_sampler_distribution(ops):
     """Distributional check of the multinomial draw (the reference's torch.multinomial stream
     cannot be reproduced; chi-square style bound on empirical frequencies)."""
