@@ -2,7 +2,9 @@
 """Benchmark of the MI355X hot path on BASELINE.json's metric.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL weight broadcast over xGMI)
+  N > 1: one rank per GPU, RCCL weight broadcast over xGMI.  Under a launcher (torch.distributed.run sets RANK /
+  WORLD_SIZE) this process IS a rank; without one it starts its own N ranks as a child job before touching the GPU
+  (mgea/launch.py) and exits with that job's code.  WORLD_SIZE != N is an error, never a silent smaller run.
 
 A "step" = one pass of the hot path over one batch of synthetic input = one greedy generation of
 configs[2]: Decoder-S (6L / 512d / 8H, V = 8324, random weights), batch 64 per GPU, 5-token
@@ -11,8 +13,10 @@ re-fed last prompt token).  value = generated MIDI tokens / s over all ranks, in
 resident in HBM, timed with barrier + torch.cuda.synchronize() on both sides, max over ranks.
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
 kernel (paged decode attention; HIP events on the launch stream) and `cpu_baseline` (the oracle =
-CPU port of the reference semantics, timed on this host's cores).  DistilBERT prompts/s (the
-other half of BASELINE.json's metric) is reported under "extra".
+CPU port of the reference semantics, timed on this host's cores).  Under "extra": DistilBERT prompts/s (the
+other half of BASELINE.json's metric; f32 parity mode and bf16), the [64, 1024] decoder prefill against the MFMA
+peak, BASELINE configs[4] (12L / 768d, top-p 0.9, 2048 tokens, fp16 storage) on one GPU, the headline generation
+in fp16 storage and at B = 256.
 """
 import argparse
 import json
@@ -30,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+PMC_FILES = ("r2_pmc_fetch_size_full.json", "r1_v6_pmc_fetch_size_full.json")   # newest committed FETCH_SIZE pass first
 
 DEC = dict(vocab=8324, seq_len=1024, d_model=512, n_layer=6, d_ff=2048)   # train/train_large2.py:10-12,23-28
 N_HEAD = 8                                                                 # api_cache.py:112
@@ -47,7 +52,10 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=16, help="HIP-event profile every n-th decode step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-bert", action="store_true", help="skip the DistilBERT extra")
+    ap.add_argument("--no-extra", action="store_true", help="skip every extra (prefill, Decoder-L, fp16, B=256, DistilBERT)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only: ranks rendezvous, broadcast a small arena and print the line; no GPU work (CPU test)")
     return ap.parse_args()
 
 
@@ -144,8 +152,118 @@ def large_batch_extra(arena, device, B, Tp, TL):
             "graph_nodes": nodes, "note": "same model, prompts of the same shape, greedy; not the BASELINE configuration (B = 64)"}
 
 
+def whole_step_bytes(geo, B, Tp, n_steps, e_w, e_kv):
+    """per step the projection / head parameters once (e_w bytes each) + every cached K/V element read once
+    and the new token's K/V written (e_kv bytes each); ctx includes the duplicated last prompt token."""
+    C_, NL, V = geo["d_model"], geo["n_layer"], geo["vocab"]
+    p_step = NL * (12 * C_ * C_ + 13 * C_) + V * C_ + V
+    return sum(p_step * e_w + B * NL * 2 * C_ * e_kv * (Tp + i + 1 + 1) for i in range(n_steps))
+
+
+def prefill_extra(arena, device, B=64, T=1024, reps=3):
+    """north_star: ">= 50 % MFMA-roofline on prefill".  Decoder-S [64, 1024] non-causal prefill with the logits of every
+    position (api_cache.py:87-106 returns them; SURVEY §8d: 3.86 TFLOP = dense 3.03 + attention 0.82)."""
+    from mgea import synth
+    from mgea.decoder import DecoderEngine
+    eng = DecoderEngine(None, n_head=N_HEAD, max_batch=B, max_ctx=T, device=device, geometry=DEC, arena=arena)
+    ids = torch.from_numpy(synth.integers(1, "prefill", (B, T), 0, DEC["vocab"])).to(device=device, dtype=torch.int32)
+    out = {}
+    C_, NL, V = DEC["d_model"], DEC["n_layer"], DEC["vocab"]
+    for name, want_logits in (("with_logits", True), ("cache_fill_only", False)):
+        eng.reset_and_prefill(ids, want_logits=want_logits)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lg = eng.reset_and_prefill(ids, want_logits=want_logits)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        del lg
+        flops = 2 * B * T * (NL * 12 * C_ * C_ + (V * C_ if want_logits else 0)) + 4 * B * T * T * C_ * NL
+        out[name] = dict(ms=dt * 1e3, tokens_per_sec=B * T / dt, tflops=flops / dt / 1e12, algorithmic_tflop=flops / 1e12,
+                         frac_of_f32_mfma_peak=flops / dt / 1e12 / 157.3)
+    eng.close()
+    w = out["with_logits"]
+    return dict(metric="decoder_prefill_tokens_per_sec", value=w["tokens_per_sec"], unit="tokens/s", ms=w["ms"], dtype="f32",
+                workload=f"Decoder-S non-causal prefill, ids [{B}, {T}], logits for every position, empty cache, random weights",
+                roofline=dict(bound="mfma", achieved=w["tflops"], peak=157.3, unit="TFLOP/s", frac=w["frac_of_f32_mfma_peak"], traffic=None,
+                              note="exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the f32 matrix peak is 157.3 TFLOP/s, 1/16 of the bf16 one"),
+                cache_fill_only=out["cache_fill_only"])
+
+
+DEC_L = dict(vocab=8324, seq_len=2048, d_model=768, n_layer=12, d_ff=3072)   # BASELINE configs[4]; 12 heads x 64 (SURVEY §8)
+
+
+def decoder_gen_extra(device, geo, n_head, B, Tp, TL, dtype, sampler, arena=None, seed=5, note=""):
+    """One warm-up + one timed generation of a decoder configuration; whole-step algorithmic bytes vs the HBM peak."""
+    from mgea import synth
+    from mgea.decoder import DecoderEngine
+    sd = None if arena is not None else synth.decoder_state_dict(seed, geo["vocab"], geo["seq_len"], geo["d_model"], geo["n_layer"])
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=B, max_ctx=TL, device=device, geometry=geo if arena is not None else None,
+                        arena=arena, dtype=dtype)
+    prompts = torch.from_numpy(synth.integers(9, "prompts", (B, Tp), 0, geo["vocab"])).to(device=device, dtype=torch.int32)
+    eng.generate(prompts, TL - Tp, **sampler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = eng.generate(prompts, TL - Tp, **sampler)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    assert int(out.min()) >= 0 and int(out.max()) < geo["vocab"]
+    eng.close()
+    e = 2 if dtype == "f16" else 4
+    nbytes = whole_step_bytes(geo, B, Tp, TL - Tp, e, e)
+    return {"metric": "midi_tokens_per_sec", "value": B * (TL - Tp) / dt, "unit": "tokens/s", "dtype": dtype, "batch": B,
+            "ms_per_generation": dt * 1e3, "us_per_step": dt / (TL - Tp) * 1e6,
+            "whole_step_hbm_frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_gb": nbytes / 1e9,
+            "graph_nodes": st["graph_nodes"], "sampler": {k: v for k, v in sampler.items() if k != "seed"},
+            "workload": f"{geo['n_layer']}L/{geo['d_model']}d/{n_head}H V={geo['vocab']} B={B} prompt {Tp} total_len {TL}, random weights",
+            "note": note}
+
+
+def dry_run(args, backend):
+    """The launch path without a GPU: rendezvous, one arena broadcast, barrier, max-reduce, one JSON line."""
+    import torch.distributed as dist
+    from mgea import dist as mdist
+    from mgea import synth
+    rank, world, _ = mdist.init_from_env(backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
+    n = 1 << 16
+    arena = torch.from_numpy(synth.uniform(9, "arena", (n,))) if rank == 0 else torch.zeros(n)
+    mdist.broadcast_arena(arena, 0)
+    ok = bool(np.array_equal(arena.numpy(), synth.uniform(9, "arena", (n,))))
+    if world > 1:
+        dist.barrier()
+    dt = mdist.all_reduce_max(1e-3 * (rank + 1), "cpu")
+    assert ok and abs(dt - 1e-3 * world) < 1e-12
+    if rank == 0:
+        print(json.dumps({"metric": "midi_tokens_per_sec", "value": 0.0, "unit": "tokens/s", "n_gpus": world, "steps": 0, "warmup": 0,
+                          "dry_run": True, "backend": dist.get_backend() if world > 1 else None, "scaling": "weak",
+                          "config": {"workload": "launch-path rehearsal: no GPU work", "parallelism": parallelism_label(world, backend, n * 4, 0.0)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def parallelism_label(world, backend, nbytes, seconds):
+    lib = "RCCL" if backend == "nccl" else backend
+    if world == 1:
+        return "1 GPU (no collective)"
+    return f"dp{world} replicas, one {lib} weight broadcast ({nbytes / 1e6:.1f} MB, {seconds * 1e3:.1f} ms), no collective in decode"
+
+
 def main():
     args = parse()
+    backend = os.environ.get("MGEA_DIST_BACKEND", "nccl")
+    from mgea import launch
+    if args.gpus > 1 and not launch.launched_by_a_launcher():
+        # no launcher: start the N ranks ourselves, BEFORE anything initialises the GPU in this process
+        # (torch.cuda.device_count() does not, on this image)
+        ndev = torch.cuda.device_count()
+        raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, backend, None if args.dry_run else ndev))
+    if args.dry_run:
+        return dry_run(args, backend)
     from mgea import dist as mdist
     from mgea import synth
     from mgea.decoder import DecoderEngine, arena_layout
@@ -154,13 +272,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     # production: "nccl" (= RCCL over xGMI), one rank per GPU.  MGEA_DIST_BACKEND=gloo rehearses the
     # N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices round-robin).
-    backend = os.environ.get("MGEA_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if backend != "nccl":
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev))
     rank, world, local = mdist.init_from_env(backend)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the job must have exactly one rank per GPU")
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -218,19 +337,24 @@ def main():
         a = prof["attn_paged"]
         if a["launches"] > 0 and a["ms"] > 0:
             ach = bytes_total / (a["ms"] * 1e-3) / 1e9
-            # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE run of this command's
-            # eager twin (profiles/README.md): mean FETCH_SIZE x 1024 x 2 (gfx950 half-count correction)
-            traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r1_v6_pmc_fetch_size_full.json")
-            if os.path.exists(pmc):
-                for k, v in json.load(open(pmc)).items():
-                    if "attn_paged_kernel" in k:
+            # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 pass, and rocprofv3
+            # --pmc aborts under hipGraph replay on this stack: profiles/README.md).  It is the constant of the committed
+            # PMC pass over this command's eager twin, named as such: mean FETCH_SIZE [KB] x 1024 x 2 (gfx950 counts
+            # half of a wide coalesced stream, MI355X_MICROARCH.md HBM section).
+            traffic, traffic_source = None, None
+            for name in PMC_FILES:
+                pmc = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc):
+                    continue
+                rec = json.load(open(pmc))
+                for k, v in rec.items():
+                    if "attn_paged_kernel" in k and isinstance(v, dict):
                         traffic = v["mean"] * 1024 * 2
-                        traffic_note = ("mean over all 6114 attention launches of the same generation run eagerly "
-                                        "(MGEA_DECODER_NOGRAPH=1: rocprofv3 --pmc crashes under hipGraph replay); "
-                                        "the 3 % above the algorithmic bytes is the whole-page K read of the first, speculative tile at contexts <= 256 and line granularity")
+                        traffic_source = (f"committed PMC constant profiles/{name} @ {rec.get('_commit', 'round-1 commit 81e2dc6')}: rocprofv3 --pmc "
+                                          f"FETCH_SIZE over the same generation run eagerly (MGEA_DECODER_NOGRAPH=1), mean of {v.get('n', 6114)} launches")
+                break
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=traffic, traffic_note=traffic_note, kernel="attn_paged_kernel<64>", launches=a["launches"],
+                        traffic=traffic, traffic_source=traffic_source, kernel="attn_paged_kernel<64>", launches=a["launches"],
                         avg_launch_us=a["ms"] * 1e3 / a["launches"],
                         algorithmic_bytes_per_launch=bytes_total / a["launches"],
                         step_breakdown_ms={k: round(v["ms"] / max(1, len(prof_steps)), 4) for k, v in prof.items()})
@@ -240,9 +364,7 @@ def main():
         gen = out.cpu()
         assert int(gen.min()) >= 0 and int(gen.max()) < DEC["vocab"]
         # whole-step algorithmic bytes: weights once per step + KV read + KV write
-        C_, NL, V = DEC["d_model"], DEC["n_layer"], DEC["vocab"]
-        p_step = NL * (12 * C_ * C_ + 13 * C_) + V * C_ + V
-        step_bytes = sum(p_step * 4 + B * NL * 2 * C_ * 4 * (Tp + i + 1 + 1) for i in range(n_steps))
+        step_bytes = whole_step_bytes(DEC, B, Tp, n_steps, 4, 4)
         line = {
             "metric": "midi_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -251,8 +373,7 @@ def main():
             "config": {"workload": f"Decoder-S 6L/512d/8H V=8324 greedy decode (sample_kvcache semantics), "
                                    f"B={B}/GPU, prompt {Tp}, total_len {TL} ({n_steps} decode steps), random weights",
                        "global_batch": B * world, "seq_len": TL,
-                       "parallelism": f"dp{world} replicas, one RCCL weight broadcast ({total * 4 / 1e6:.1f} MB, "
-                                      f"{t_bcast * 1e3:.1f} ms), no collective in decode"},
+                       "parallelism": parallelism_label(world, backend, total * 4, t_bcast)},
             "tokens_per_sec_per_gpu": value / world,
             "whole_step_hbm_frac": step_bytes * args.steps / (dt) / 1e9 / HBM_PEAK_GBS,
             "graph": eng.stats(),
@@ -260,12 +381,27 @@ def main():
         }
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_decoder(sd, prompts.tolist(), args.cpu_seconds)
-        if not args.no_bert:
-            line["extra"] = {"distilbert": bert_extra(device, max(2, args.steps), 1, not args.no_cpu),
-                             "distilbert_bf16": bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")}
-            if world == 1:   # informational: the same generation at 4x the batch per GPU (still the fused 32-launch step)
-                line["extra"]["decoder_batch256"] = large_batch_extra(arena, device, 256, Tp, TL)
-    eng.close()
+        extra = {}
+        if not args.no_bert and not args.no_extra:
+            extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu)
+            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")
+        if world == 1 and not args.no_extra:
+            eng.close()
+            eng = None
+            extra["decoder_prefill"] = prefill_extra(arena, device)
+            # BASELINE configs[4] as written: fp16 storage, top-p 0.9, 2048 tokens, captured step graph (one GPU's share)
+            top_p = dict(temperature=1.0, top_k=None, top_p=0.9, seed=1)
+            extra["decoder_L"] = decoder_gen_extra(device, DEC_L, 12, 64, 5, 2048, "f16", top_p,
+                                                   note="BASELINE configs[4] per GPU: fp16 weights + KV, fp32 accumulate; sampled (ids are not a parity claim)")
+            extra["decoder_L_f32"] = decoder_gen_extra(device, DEC_L, 12, 64, 5, 2048, "f32", top_p, note="same, fp32 parity-mode storage")
+            extra["decoder_S_f16"] = decoder_gen_extra(device, DEC, N_HEAD, B, Tp, TL, "f16", dict(temperature=1.0, top_k=1), arena=arena,
+                                                       note="the headline generation in fp16 storage (perf mode, not the parity mode)")
+            # informational: the headline generation at 4x the batch per GPU (still the fused 32-launch step)
+            extra["decoder_batch256"] = large_batch_extra(arena, device, 256, Tp, TL)
+        if extra:
+            line["extra"] = extra
+    if eng is not None:
+        eng.close()
     barrier()
     if rank == 0:
         print(json.dumps(line))

@@ -13,7 +13,7 @@ from mgea import synth
 from mgea.bert import resolve_adapter
 from oracle.distilbert_ref import DistilBertRef
 
-D, HID, NL, H = 64, 128, 2, 4
+D, HID, NL, H = 64, 128, 2, 2      # head_dim 32: the smallest the HIP attention kernels take
 
 
 def base_sd():

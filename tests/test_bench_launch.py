@@ -1,0 +1,56 @@
+"""bench.py's own launch path at world size 2 over gloo, on CPU (`python bench.py --gpus N` used to run ONE
+rank and print n_gpus 1).  `--dry-run` keeps everything of the N-rank flow except the GPU work: the parent starts
+N children through torch.distributed.run, the ranks rendezvous on 127.0.0.1, broadcast an arena, barrier,
+max-reduce and rank 0 prints the one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, **env):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH, *args], env=e, capture_output=True, text=True, timeout=600)
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}: {stdout[-400:]}"
+    return json.loads(lines[0])
+
+
+def test_gpus2_without_a_launcher_starts_two_ranks():
+    r = run(["--gpus", "2", "--dry-run"], MGEA_DIST_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-800:]
+    line = last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["backend"] == "gloo"
+    assert "gloo weight broadcast" in line["config"]["parallelism"] and "RCCL" not in line["config"]["parallelism"]
+
+
+def test_rccl_job_on_too_few_gpus_fails_loudly_instead_of_running_one_rank():
+    r = run(["--gpus", "2"])                      # backend nccl (default); this container has no GPU at all
+    assert r.returncode != 0
+    assert "needs 2 visible GPUs" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_mismatch_is_an_error():
+    r = run(["--gpus", "2", "--dry-run"], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MGEA_DIST_BACKEND="gloo")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_launcher_command_is_the_drivers():
+    sys.path.insert(0, os.path.join(ROOT, "music-generation-emotion-adaptive_amd"))
+    from mgea import launch
+    cmd = launch.rank_command("bench.py", ["--gpus", "4"], 4, port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                       "--master-port", "29511", "bench.py", "--gpus", "4"]
+    with pytest.raises(ValueError):
+        launch.spawn_ranks("bench.py", [], 1)
