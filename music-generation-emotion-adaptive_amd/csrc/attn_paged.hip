@@ -14,18 +14,31 @@
 //   PV   : lane = (token group g, 16-byte d-chunk c).  V page is [64 tokens][dh]: a wave
 //          instruction reads 64/(dh/4) whole rows (1 KiB contiguous); p is fetched from the lane
 //          that owns the token with one bpermute per load.
-// Algorithmic bytes per (b, h): 2 * ctx * dh * 4 (K and V each streamed once).
+// Algorithmic bytes per (b, h): 2 * ctx * dh * 4 (K and V each streamed once); half of that with fp16 pages.
+//
+// F16 (MGEA_DTYPE_F16 engines): the pages hold _Float16 with the same two layouts at 16-byte granularity (a group is 8
+// elements instead of 4: K [dh/8][64 tokens][8], V [64 tokens][dh]), so every wave load is still 1 KiB of consecutive
+// bytes and carries twice the tokens x dims.  q, the scores, the softmax and the output accumulators stay fp32; K/V
+// elements are widened in the FMA (v_fma_mix_f32).
 #include "common.h"
 
 namespace mgea {
 
-template <int DH>
+template <bool F16>
+__device__ __forceinline__ float kv_elem(const f32x4& raw, int j) {
+    if (F16) return (float)__builtin_bit_cast(h16x8, raw)[j];
+    return raw[j];
+}
+
+template <int DH, bool F16>
 __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict__ qkv, KvPool pool, int layer,
                                                         const int32_t* __restrict__ page_table, int max_pages,
                                                         const int32_t* __restrict__ ctx_len,
                                                         const int32_t* __restrict__ lens, float* __restrict__ out,
                                                         int H, int T, int C, float scale, int tiled_out) {
-    constexpr int NCH = DH / 4;        // 16-byte chunks per head row
+    constexpr int G = F16 ? 8 : 4;     // elements per 16-byte group
+    constexpr int EB = F16 ? 2 : 4;    // bytes per element
+    constexpr int NCH = DH / G;        // 16-byte chunks per head row
     constexpr int TPI = 64 / NCH;      // tokens per V wave-instruction (head_dim 96: 2 tokens x 24 chunks, 16 lanes idle)
     constexpr int NVI = 64 / TPI;      // V wave-instructions per page
     constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
@@ -39,29 +52,30 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t m = (int64_t)b * T + t;
-    const int64_t pf = pool.page_floats();
-    const float* lbase = pool.base + layer * pool.layer_stride;
+    const int64_t pf = pool.page_elems();
+    const char* lbase = static_cast<const char*>(pool.base) + layer * pool.layer_stride * EB;
     const int g = lane / NCH, c = lane % NCH;
     const bool v_lane = g < TPI;       // lanes past TPI * NCH (head_dim 96) take no part in PV
 
     // Software pipeline over this wave's pages: while QK^T consumes K(page) the V(page) loads are in
     // flight, and while PV consumes V(page) the K(next page) loads are -- each wave keeps 16 KiB
     // (one operand tile) streaming at all times.  K/V are read once per step: non-temporal loads.
-    float4 kk[NCH], vv[NVI];
+    f32x4 kk[NCH], vv[NVI];   // raw 16-byte groups: 4 floats or 8 halves
     auto page_base = [&](int pg, int isv) {
         const int phys = page_table[b * max_pages + pg];
-        return lbase + ((int64_t)(phys * 2 + isv) * H + h) * pf;
+        return lbase + ((int64_t)(phys * 2 + isv) * H + h) * pf * EB;
     };
+    auto ldraw = [](const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); };
     // n_tok = tokens of the page that are in the cache: lanes (= tokens) past the end of the last, partial page
     // re-read the last cached token instead of their own slot -- a wave instruction is 1 KiB of consecutive bytes,
     // so the tail of the page is never fetched from HBM (whole-page reads cost 8 % extra traffic on the benchmark
     // run).  Clamped addresses rather than predication: a load inside a branch makes the compiler drain vmcnt to 0
     // at the next use and the K/V pipelining below is lost.
     auto load_k = [&](int pg, int n_tok) {
-        const float* kpage = page_base(pg, 0);
+        const char* kpage = page_base(pg, 0);
         const int tok = lane < n_tok ? lane : n_tok - 1;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) kk[i] = ldnt4(kpage + (i * 64 + tok) * 4);
+        for (int i = 0; i < NCH; ++i) kk[i] = ldraw(kpage + (i * 64 + tok) * 16);
     };
     // The first K tile is requested before anything else is known: its page index depends only on the
     // wave id, so the page-table -> K round trips overlap the ctx_len / q fetches (the kernel's fixed
@@ -84,28 +98,26 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     for (int d = 0; d < DH; ++d) q[d] = qp[d] * scale;  // 1/sqrt(64) etc.: power-of-two scales are exact
 
     float mx = -INFINITY, lsum = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) acc[e] = 0.f;
 
     for (int pg = wave; pg < npages; pg += 4) {
-        const float* vpage = page_base(pg, 1);
+        const char* vpage = page_base(pg, 1);
         const int n_tok = len - pg * 64;   // >= 1; > 64 for a full page
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {   // rows beyond the cache end: the last cached row instead (their p is 0)
             const int row = v_lane ? j * TPI + g : 0;
-            vv[j] = ldnt4(vpage + (row < n_tok ? row : n_tok - 1) * DH + c * 4);
+            vv[j] = ldraw(vpage + ((row < n_tok ? row : n_tok - 1) * DH + c * G) * EB);
         }
 
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f;   // two chains; fp32: the same order as before (groups alternate between them)
 #pragma unroll
         for (int i = 0; i < NCH; i += 2) {
-            s0 = fmaf(q[4 * i + 0], kk[i].x, s0);
-            s0 = fmaf(q[4 * i + 1], kk[i].y, s0);
-            s0 = fmaf(q[4 * i + 2], kk[i].z, s0);
-            s0 = fmaf(q[4 * i + 3], kk[i].w, s0);
-            s1 = fmaf(q[4 * i + 4], kk[i + 1].x, s1);
-            s1 = fmaf(q[4 * i + 5], kk[i + 1].y, s1);
-            s1 = fmaf(q[4 * i + 6], kk[i + 1].z, s1);
-            s1 = fmaf(q[4 * i + 7], kk[i + 1].w, s1);
+#pragma unroll
+            for (int e = 0; e < G; ++e) s0 = fmaf(q[G * i + e], kv_elem<F16>(kk[i], e), s0);
+#pragma unroll
+            for (int e = 0; e < G; ++e) s1 = fmaf(q[G * (i + 1) + e], kv_elem<F16>(kk[i + 1], e), s1);
         }
         const bool valid = (pg * 64 + lane) < len;
         const float s = valid ? (s0 + s1) : -INFINITY;
@@ -114,46 +126,42 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         const float alpha = __expf(mx - mnew);     // first tile: exp(-inf) = 0
         const float p = valid ? __expf(s - mnew) : 0.f;
         lsum = lsum * alpha + p;
-        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+#pragma unroll
+        for (int e = 0; e < G; ++e) acc[e] *= alpha;
         mx = mnew;
         if (pg + 4 < npages) load_k(pg + 4, len - (pg + 4) * 64);  // K registers are free again: next page's K under PV
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {
             const float pv = __shfl(p, j * TPI + g, 64);
             const float pj = v_lane ? pv : 0.f;
-            acc.x = fmaf(pj, vv[j].x, acc.x);
-            acc.y = fmaf(pj, vv[j].y, acc.y);
-            acc.z = fmaf(pj, vv[j].z, acc.z);
-            acc.w = fmaf(pj, vv[j].w, acc.w);
+#pragma unroll
+            for (int e = 0; e < G; ++e) acc[e] = fmaf(pj, kv_elem<F16>(vv[j], e), acc[e]);
         }
     }
     // reduce the token groups g (lanes c, c+NCH, ...) and the per-lane softmax sums
     if (POW2) {
 #pragma unroll
         for (int o = 32; o >= NCH; o >>= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64);
-            acc.y += __shfl_xor(acc.y, o, 64);
-            acc.z += __shfl_xor(acc.z, o, 64);
-            acc.w += __shfl_xor(acc.w, o, 64);
+#pragma unroll
+            for (int e = 0; e < G; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
         }
     } else {   // lanes c < NCH collect the other token groups in a fixed order
-        float4 tot = acc;
+        float tot[G];
+#pragma unroll
+        for (int e = 0; e < G; ++e) tot[e] = acc[e];
 #pragma unroll
         for (int gg = 1; gg < TPI; ++gg) {
-            tot.x += __shfl(acc.x, lane + gg * NCH, 64);
-            tot.y += __shfl(acc.y, lane + gg * NCH, 64);
-            tot.z += __shfl(acc.z, lane + gg * NCH, 64);
-            tot.w += __shfl(acc.w, lane + gg * NCH, 64);
+#pragma unroll
+            for (int e = 0; e < G; ++e) tot[e] += __shfl(acc[e], lane + gg * NCH, 64);
         }
-        acc = tot;
+#pragma unroll
+        for (int e = 0; e < G; ++e) acc[e] = tot[e];
     }
     lsum = wave_sum(lsum);
     if (lane == 0) { s_m[wave] = mx; s_l[wave] = lsum; }
     if (lane < NCH) {
-        s_acc[wave][4 * lane + 0] = acc.x;
-        s_acc[wave][4 * lane + 1] = acc.y;
-        s_acc[wave][4 * lane + 2] = acc.z;
-        s_acc[wave][4 * lane + 3] = acc.w;
+#pragma unroll
+        for (int e = 0; e < G; ++e) s_acc[wave][G * lane + e] = acc[e];
     }
     __syncthreads();
     if (threadIdx.x < DH) {
@@ -177,14 +185,26 @@ int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int
     MGEA_REQUIRE(T <= 65535, MGEA_EINVAL, "attention: too many new tokens per row (%d)", T);
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(B * H, T);
-    switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_paged_kernel<32>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
-        case 64: hipLaunchKernelGGL(attn_paged_kernel<64>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
-        case 96: hipLaunchKernelGGL(attn_paged_kernel<96>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
-        case 128: hipLaunchKernelGGL(attn_paged_kernel<128>, grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out); break;
-        default:
-            MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 96, 128)", dh);
+#define MGEA_ATTN(DH, F) hipLaunchKernelGGL((attn_paged_kernel<DH, F>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out)
+    if (pool.f16) {
+        switch (dh) {
+            case 32: MGEA_ATTN(32, true); break;
+            case 64: MGEA_ATTN(64, true); break;
+            case 128: MGEA_ATTN(128, true); break;
+            default:
+                MGEA_REQUIRE(false, MGEA_EINVAL, "attention over fp16 KV pages: head_dim %d not supported (32, 64, 128)", dh);
+        }
+    } else {
+        switch (dh) {
+            case 32: MGEA_ATTN(32, false); break;
+            case 64: MGEA_ATTN(64, false); break;
+            case 96: MGEA_ATTN(96, false); break;
+            case 128: MGEA_ATTN(128, false); break;
+            default:
+                MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 96, 128)", dh);
+        }
     }
+#undef MGEA_ATTN
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

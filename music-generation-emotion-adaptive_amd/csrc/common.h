@@ -59,6 +59,15 @@ __host__ __device__ static inline int64_t tiled_off(int row, int n, int N) {
 // rows are padded to a multiple of 32 with zeros.  Built once per engine from the arena (launch_tile_weights).
 static inline int64_t wtile_floats(int N, int K) { return round_up(N, 32) * (int64_t)K; }
 int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st, const float* gamma = nullptr);
+// fp16 twin (MGEA_DTYPE_F16): per (16-row tile, 32-wide k-chunk) one 1 KB block [lane = 16 g + c][8] of _Float16 holding
+// W[tile * 16 + c][chunk * 32 + 8 g + 0..7] -- the A/B fragment of v_mfma_f32_16x16x32_f16; out has wtile_floats(N, K) halves
+int launch_tile_weights_f16(const float* W, int N, int K, void* out, hipStream_t st);
+// c1[n] = sum_k gamma[k] * W[n,k], c2[n] = sum_k beta[k] * W[n,k] + bias[n] (fp64 sums of exact products): the folded-LayerNorm
+// vectors when gamma is applied on the activation side (fp16 mode)
+int launch_ln_vectors(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, float* c1, float* c2,
+                      hipStream_t st);
+// x[i] <- float(half(x[i])) in place (round-to-nearest-even): the fp16 engine's private fp32 copy of the matrices
+int launch_round_f16_inplace(float* x, int64_t n, hipStream_t st);
 // LayerNorm folded into the matrix it feeds: out = tiles of gamma[k] * W[n,k]; c1[n] = sum_k of those products,
 // c2[n] = sum_k beta[k] * W[n,k] + bias[n] (sums in fp64, once per engine)
 int launch_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, float* out,
@@ -93,12 +102,19 @@ int launch_bias_res_ln(const float* P, int S, int64_t ps, int ldp, const float* 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int C, float eps,
                      hipStream_t st);
 
+// Paged KV pool: [n_layer][n_pages][K | V][H][one page = 64 tokens x dh elements]; elements are fp32 (parity mode) or
+// fp16 (MGEA_DTYPE_F16).  Inside a page, with G = the elements of one 16-byte group (4 floats / 8 halves):
+//   K: [dh / G][64 tokens][G]  (token-major inside a d-group: in the decode kernel lane = token, every wave load
+//                               instruction is 1 KiB of consecutive bytes)
+//   V: [64 tokens][dh]         (a wave instruction reads 1 KiB = several whole rows)
 struct KvPool {
-    float* base;          // [n_layer][n_pages][2][H][64*dh]
+    void* base;
     int32_t n_pages;      // physical pages per layer
     int32_t H, dh;
-    int64_t layer_stride; // floats
-    __host__ __device__ int64_t page_floats() const { return (int64_t)MGEA_KV_PAGE_TOKENS * dh; }
+    int64_t layer_stride; // elements
+    int32_t f16;          // 0: float elements, 1: _Float16 elements
+    __host__ __device__ int64_t page_elems() const { return (int64_t)MGEA_KV_PAGE_TOKENS * dh; }
+    __host__ __device__ int elt_bytes() const { return f16 ? 2 : 4; }
 };
 
 // decoder embedding: x[m] = tok_emb[ids[m]] + pos_emb[pos]; xn = LN(x) if lnw.
@@ -195,13 +211,16 @@ enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
 
 struct SkinnyArgs {
     const float* A; int lda;
-    const float* W;            // [N, K] in the tiled weight layout (launch_tile_weights)
+    const float* W;            // [N, K] in the tiled weight layout (launch_tile_weights); fp16 tiles (launch_tile_weights_f16) if w_f16
+    int w_f16;                 // MGEA_DTYPE_F16 engines: W holds _Float16 fragments, A is rounded to fp16 on load, f16 MFMA, fp32 accumulate
     const float* bias;         // [N] or NULL
     int M, N, K;
     // folded LayerNorm (ln_c1 != NULL): W holds gamma * W, ln_c1 [N] = its row sums, bias = beta @ W^T + bias
     // (launch_ln_fold); per-row partial stats [64][n_part][2], each over `part_cnt` elements
     const float* ln_c1; float eps;
-    const float* ln_g; const float* ln_b;   // launch_gemv only: LayerNorm gamma / beta applied directly (W row-major, unfolded)
+    const float* ln_g; const float* ln_b;   // launch_gemv: LayerNorm gamma / beta applied directly (W row-major, unfolded);
+                                            // w_f16 with ln_c1: gamma is applied to A on load (W stays the plain rounded matrix,
+                                            // ln_c1 = sum_k gamma_k W[n,k], bias = sum_k beta_k W[n,k] + b[n])
     const float* stats_in; int n_part; int part_cnt;
     // outputs
     float* out; int ldo;       // QKV: qkv_out [M, N]; RES: x [M, N] (in place); ACT: out [M, ldo]; LOGITS: logits or NULL
@@ -256,6 +275,25 @@ __device__ __forceinline__ float4 ldnt4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+// 8 floats -> 8 halves, round-to-nearest-even (v_cvt_f16_f32)
+__device__ __forceinline__ h16x8 to_h8(float4 a, float4 b) {
+    return (h16x8){(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+}
+// the 4 consecutive elements d .. d+3 (d % 4 == 0) of head `head`, token slot `slot`, of the K (isv = 0) or V page `phys`
+__device__ __forceinline__ void kv_store4(const KvPool& pool, int layer, int phys, int isv, int head, int slot, int d, float4 v) {
+    const int64_t pe = pool.page_elems();
+    const int64_t page = layer * pool.layer_stride + ((int64_t)(phys * 2 + isv) * pool.H + head) * pe;
+    if (pool.f16) {
+        _Float16* p = static_cast<_Float16*>(pool.base) + page + (isv ? slot * pool.dh + d : ((d >> 3) * MGEA_KV_PAGE_TOKENS + slot) * 8 + (d & 7));
+        *reinterpret_cast<h16x4*>(p) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    } else {
+        float* p = static_cast<float*>(pool.base) + page + (isv ? slot * pool.dh + d : ((d >> 2) * MGEA_KV_PAGE_TOKENS + slot) * 4);
+        st4(p, v);
+    }
+}
 
 // End of a decode step for row b, by one 256-thread workgroup whose thread 0 holds the new token `tok`:
 // the sampler-loop bookkeeping of api_cache.py:179-181 (append, EOS stop) and the NEXT step's embedding

@@ -54,15 +54,29 @@ int validate(const mgea_decoder_config* c) {
     // the sampler keeps a row of logits in registers; refuse at create rather than at the first sampled generate()
     MGEA_REQUIRE(c->vocab <= MGEA_SAMPLER_MAX_VOCAB, MGEA_EINVAL, "vocab %d exceeds the sampler's limit of %d", c->vocab,
                  MGEA_SAMPLER_MAX_VOCAB);
-    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32, MGEA_EINVAL, "decoder dtype %d not built (f32 only in this build)", c->dtype);
+    MGEA_REQUIRE(c->dtype == MGEA_DTYPE_F32 || c->dtype == MGEA_DTYPE_F16, MGEA_EINVAL,
+                 "decoder dtype %d not supported (MGEA_DTYPE_F32 or MGEA_DTYPE_F16)", c->dtype);
     MGEA_REQUIRE(c->block_mode == MGEA_BLOCK_PRELN_GELU || c->block_mode == MGEA_BLOCK_POSTLN_RELU, MGEA_EINVAL, "bad block_mode");
+    if (c->dtype == MGEA_DTYPE_F16) {   // the fp16 mode lives on the fused decode path (tiled fp16 matrices, fp16 KV pages)
+        MGEA_REQUIRE(c->block_mode == MGEA_BLOCK_PRELN_GELU, MGEA_EINVAL, "MGEA_DTYPE_F16 needs the KV-cache block mode");
+        MGEA_REQUIRE((c->d_model % 128) == 0 && c->d_model >= 256 && c->d_model <= 1024, MGEA_EINVAL,
+                     "MGEA_DTYPE_F16 needs d_model in 256..1024, a multiple of 128 (got %d)", c->d_model);
+        MGEA_REQUIRE(dh == 32 || dh == 64, MGEA_EINVAL, "MGEA_DTYPE_F16 needs head_dim 32 or 64 (got %d)", dh);
+    }
     return MGEA_OK;
 }
 }  // namespace
 
 struct mgea_decoder {
     mgea_decoder_config cfg{};
-    const float* arena = nullptr;
+    const float* arena = nullptr;       // what every kernel reads: the caller's arena (f32) or arena_own (f16)
+    // MGEA_DTYPE_F16: the model served is "the reference with its five projection-matrix kinds rounded to fp16".  arena_own is
+    // a private fp32 copy of the caller's arena (arena_src) with exactly those tensors rounded, so that every path that reads
+    // row-major fp32 weights (prefill beyond 512 rows, slab fallback) serves the SAME model as the fp16 tiles of the decode path.
+    const float* arena_src = nullptr;
+    float* arena_own = nullptr;
+    int64_t arena_total = 0;
+    bool f16 = false;
     std::vector<int64_t> off;
     int dh = 0;
     std::mutex mu;
@@ -108,8 +122,11 @@ struct mgea_decoder {
     const float* head_b() const { return arena + off[3 + cfg.n_layer * L_COUNT]; }
     // fragment-ordered copies of the five matrix kinds for the fused decode path (common.h: launch_tile_weights);
     // index 4 * layer + {0 in_proj, 1 out_proj, 2 fc1, 3 fc2}, then the head
-    float* wt = nullptr;
+    void* wt = nullptr;                 // fp32 fragments (f32) or _Float16 fragments (f16); offsets in elements
     std::vector<int64_t> wt_off;
+    const float* wt_at(int64_t off) const {
+        return reinterpret_cast<const float*>(static_cast<const char*>(wt) + off * (f16 ? 2 : 4));
+    }
     // LayerNorm folded into in_proj (ln1) and fc1 (ln2): those two tiled matrices hold gamma * W, and lnv holds per layer
     // [c1 3C][c2 3C][c1 F][c2 F] (common.h: launch_ln_fold)
     float* lnv = nullptr;
@@ -117,8 +134,8 @@ struct mgea_decoder {
     const float* qkv_c2(int l) const { return qkv_c1(l) + 3 * cfg.d_model; }
     const float* fc1_c1(int l) const { return qkv_c1(l) + 6 * cfg.d_model; }
     const float* fc1_c2(int l) const { return fc1_c1(l) + cfg.d_ff; }
-    const float* tw(int layer, int j) const { return wt + wt_off[4 * layer + j]; }
-    const float* head_tw() const { return wt + wt_off[4 * cfg.n_layer]; }
+    const float* tw(int layer, int j) const { return wt_at(wt_off[4 * layer + j]); }
+    const float* head_tw() const { return wt_at(wt_off[4 * cfg.n_layer]); }
 };
 
 namespace {
@@ -313,7 +330,7 @@ bool fused_ok(const mgea_decoder* h, int M) {
 // row-major arena weights instead of 16 x 16 MFMA tiles (gemv_small.hip)
 bool gemv_ok(const mgea_decoder* h, int M, int T, const int32_t* lens, bool use_cache_attn) {
     const auto& c = h->cfg;
-    return !h->no_gemv && T == 1 && !lens && use_cache_attn && gemv_shape_ok(M, c.d_model, c.d_model) &&
+    return !h->no_gemv && !h->f16 && T == 1 && !lens && use_cache_attn && gemv_shape_ok(M, c.d_model, c.d_model) &&
            gemv_shape_ok(M, c.d_model, c.d_ff);
 }
 
@@ -324,7 +341,8 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
     int n_part = 2, part_cnt = C / 2;  // the embedding kernel leaves the whole-row statistics as two equal halves
     for (int l = 0; l < c.n_layer; ++l) {
         SkinnyArgs a{};
-        a.M = M; a.eps = c.ln_eps;
+        a.M = M; a.eps = c.ln_eps; a.w_f16 = h->f16;
+        if (h->f16) a.ln_g = h->lw(l, L_LN1W);
         // ln1 + in_proj + KV append
         a.A = u.x; a.lda = C; a.W = h->tw(l, 0); a.bias = h->qkv_c2(l); a.N = 3 * C; a.K = C;
         a.ln_c1 = h->qkv_c1(l); a.stats_in = u.stats; a.n_part = n_part; a.part_cnt = part_cnt;
@@ -344,7 +362,7 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         }
         // out_proj + residual (+ stats for ln2)
         SkinnyArgs o{};
-        o.M = M; o.eps = c.ln_eps;
+        o.M = M; o.eps = c.ln_eps; o.w_f16 = h->f16;
         o.A = u.att; o.lda = C; o.W = h->tw(l, 1); o.bias = h->lw(l, L_OUTB); o.N = C; o.K = C;
         o.out = u.x; o.ldo = C; o.stats_out = u.stats;
         if (gv) {
@@ -356,7 +374,8 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         n_part = C / 16; part_cnt = 16;
         // ln2 + mlp.0 + GELU
         SkinnyArgs f{};
-        f.M = M; f.eps = c.ln_eps;
+        f.M = M; f.eps = c.ln_eps; f.w_f16 = h->f16;
+        if (h->f16) f.ln_g = h->lw(l, L_LN2W);
         f.A = u.x; f.lda = C; f.W = h->tw(l, 2); f.bias = h->fc1_c2(l); f.N = F; f.K = C;
         f.ln_c1 = h->fc1_c1(l); f.stats_in = u.stats; f.n_part = n_part; f.part_cnt = part_cnt;
         f.out = u.hbuf; f.ldo = F; f.act = ACT_GELU;
@@ -368,7 +387,7 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         }
         // mlp.2 + residual (+ stats for the next ln1)
         SkinnyArgs r{};
-        r.M = M; r.eps = c.ln_eps;
+        r.M = M; r.eps = c.ln_eps; r.w_f16 = h->f16;
         r.A = u.hbuf; r.lda = F; r.W = h->tw(l, 3); r.bias = h->lw(l, L_FC2B); r.N = C; r.K = F;
         r.out = u.x; r.ldo = C; r.stats_out = u.stats;
         if (gv) {
@@ -413,6 +432,7 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
                                           c.seq_len, abs_pos, h->err_flag, st));
     MGEA_TRY(run_blocks_fused(h, u, B, 1, nullptr, true, st));
     SkinnyArgs a{};
+    a.w_f16 = h->f16;
     a.M = B; a.A = u.x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
     a.out = logits_out ? logits_out : (greedy ? nullptr : u.logits);
     a.ldo = V; a.pmax_val = u.pmax_val; a.pmax_idx = u.pmax_idx;
@@ -581,6 +601,7 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     }
     if (logits_out && fused_ok(h, (int)M)) {
         SkinnyArgs a{};  // x is k-tiled on the fused path: the head is the skinny LOGITS kernel
+        a.w_f16 = h->f16;
         a.M = (int)M; a.A = h->x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
         a.out = logits_out; a.ldo = V;
         MGEA_TRY(launch_skinny(EPI_LOGITS, a, st));
@@ -632,23 +653,49 @@ static int build_tiled_weights(mgea_decoder* h, hipStream_t st) {
             h->wt_off.push_back(total); total += wtile_floats(C, F);
         }
         h->wt_off.push_back(total); total += wtile_floats(V, C);
-        if (hipMalloc((void**)&h->wt, (size_t)total * sizeof(float)) != hipSuccess ||
+        if (hipMalloc((void**)&h->wt, (size_t)total * (h->f16 ? 2 : 4)) != hipSuccess ||
             hipMalloc((void**)&h->lnv, (size_t)c.n_layer * (6 * C + 2 * F) * sizeof(float)) != hipSuccess) {
             if (h->wt) (void)hipFree(h->wt);
             h->wt = nullptr;
-            set_error("decoder_create: allocation of the decode-layout weights (%lld MB) failed", (long long)(total * 4 >> 20));
+            set_error("decoder_create: allocation of the decode-layout weights (%lld MB) failed", (long long)(total * (h->f16 ? 2 : 4) >> 20));
             return MGEA_ENOMEM;
         }
     }
+    if (h->f16) {
+        // private model copy: the caller's arena with the five matrix kinds rounded to fp16 (fp32 storage) ...
+        float* own = h->arena_own;
+        MGEA_CHECK_HIP(hipMemcpyAsync(own, h->arena_src, (size_t)h->arena_total * sizeof(float), hipMemcpyDeviceToDevice, st));
+        const int mats[4] = {L_INW, L_OUTW, L_FC1W, L_FC2W};
+        const int64_t msz[4] = {3ll * C * C, (int64_t)C * C, (int64_t)F * C, (int64_t)C * F};
+        for (int l = 0; l < c.n_layer; ++l)
+            for (int j = 0; j < 4; ++j) MGEA_TRY(launch_round_f16_inplace(own + h->off[2 + l * L_COUNT + mats[j]], msz[j], st));
+        MGEA_TRY(launch_round_f16_inplace(own + h->off[2 + c.n_layer * L_COUNT], (int64_t)V * C, st));
+        // ... and its fp16 fragments for the decode path; LayerNorm's gamma is applied on the activation side (gemm_skinny.hip)
+        _Float16* wt = static_cast<_Float16*>(h->wt);
+        for (int l = 0; l < c.n_layer; ++l) {
+            MGEA_TRY(launch_tile_weights_f16(h->lw(l, L_INW), 3 * C, C, wt + h->wt_off[4 * l + 0], st));
+            MGEA_TRY(launch_ln_vectors(h->lw(l, L_INW), h->lw(l, L_LN1W), h->lw(l, L_LN1B), h->lw(l, L_INB), 3 * C, C,
+                                       const_cast<float*>(h->qkv_c1(l)), const_cast<float*>(h->qkv_c2(l)), st));
+            MGEA_TRY(launch_tile_weights_f16(h->lw(l, L_OUTW), C, C, wt + h->wt_off[4 * l + 1], st));
+            MGEA_TRY(launch_tile_weights_f16(h->lw(l, L_FC1W), F, C, wt + h->wt_off[4 * l + 2], st));
+            MGEA_TRY(launch_ln_vectors(h->lw(l, L_FC1W), h->lw(l, L_LN2W), h->lw(l, L_LN2B), h->lw(l, L_FC1B), F, C,
+                                       const_cast<float*>(h->fc1_c1(l)), const_cast<float*>(h->fc1_c2(l)), st));
+            MGEA_TRY(launch_tile_weights_f16(h->lw(l, L_FC2W), C, F, wt + h->wt_off[4 * l + 3], st));
+        }
+        MGEA_TRY(launch_tile_weights_f16(h->head_w(), V, C, wt + h->wt_off[4 * c.n_layer], st));
+        MGEA_CHECK_HIP(hipStreamSynchronize(st));
+        return MGEA_OK;
+    }
+    float* wt = static_cast<float*>(h->wt);
     for (int l = 0; l < c.n_layer; ++l) {
         MGEA_TRY(launch_ln_fold(h->lw(l, L_INW), h->lw(l, L_LN1W), h->lw(l, L_LN1B), h->lw(l, L_INB), 3 * C, C,
-                                h->wt + h->wt_off[4 * l + 0], const_cast<float*>(h->qkv_c1(l)), const_cast<float*>(h->qkv_c2(l)), st));
-        MGEA_TRY(launch_tile_weights(h->lw(l, L_OUTW), C, C, h->wt + h->wt_off[4 * l + 1], st));
+                                wt + h->wt_off[4 * l + 0], const_cast<float*>(h->qkv_c1(l)), const_cast<float*>(h->qkv_c2(l)), st));
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_OUTW), C, C, wt + h->wt_off[4 * l + 1], st));
         MGEA_TRY(launch_ln_fold(h->lw(l, L_FC1W), h->lw(l, L_LN2W), h->lw(l, L_LN2B), h->lw(l, L_FC1B), F, C,
-                                h->wt + h->wt_off[4 * l + 2], const_cast<float*>(h->fc1_c1(l)), const_cast<float*>(h->fc1_c2(l)), st));
-        MGEA_TRY(launch_tile_weights(h->lw(l, L_FC2W), C, F, h->wt + h->wt_off[4 * l + 3], st));
+                                wt + h->wt_off[4 * l + 2], const_cast<float*>(h->fc1_c1(l)), const_cast<float*>(h->fc1_c2(l)), st));
+        MGEA_TRY(launch_tile_weights(h->lw(l, L_FC2W), C, F, wt + h->wt_off[4 * l + 3], st));
     }
-    MGEA_TRY(launch_tile_weights(h->head_w(), V, C, h->wt + h->wt_off[4 * c.n_layer], st));
+    MGEA_TRY(launch_tile_weights(h->head_w(), V, C, wt + h->wt_off[4 * c.n_layer], st));
     MGEA_CHECK_HIP(hipStreamSynchronize(st));
     return MGEA_OK;
 }
@@ -663,9 +710,11 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     }
     mgea_decoder* h = new mgea_decoder();
     h->cfg = *cfg;
-    h->arena = arena_dev;
+    h->arena = h->arena_src = arena_dev;
+    h->f16 = cfg->dtype == MGEA_DTYPE_F16;
     int64_t total = 0;
     arena_layout(*cfg, &h->off, &total);
+    h->arena_total = total;
     h->dh = cfg->d_model / cfg->n_head;
     {
         const char* e = getenv("MGEA_DECODER_UNFUSED");
@@ -680,13 +729,19 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     h->kv.n_pages = cfg->max_batch * h->pages_per_row_cap;
     h->kv.H = cfg->n_head;
     h->kv.dh = h->dh;
-    h->kv.layer_stride = (int64_t)h->kv.n_pages * 2 * cfg->n_head * h->kv.page_floats();
-    const size_t pool_bytes = (size_t)h->kv.layer_stride * cfg->n_layer * sizeof(float);
+    h->kv.f16 = h->f16 ? 1 : 0;
+    h->kv.layer_stride = (int64_t)h->kv.n_pages * 2 * cfg->n_head * h->kv.page_elems();
+    const size_t pool_bytes = (size_t)h->kv.layer_stride * cfg->n_layer * h->kv.elt_bytes();
     auto fail = [&](int code, const char* what) {
         set_error("decoder_create: %s", what);
         mgea_decoder_destroy(h);
         return code;
     };
+    if (h->f16) {
+        if (hipMalloc((void**)&h->arena_own, (size_t)total * sizeof(float)) != hipSuccess)
+            return fail(MGEA_ENOMEM, "allocation of the fp16-rounded model copy failed");
+        h->arena = h->arena_own;   // filled by build_tiled_weights below
+    }
     if (cfg->block_mode == MGEA_BLOCK_PRELN_GELU) {
         if (hipMalloc((void**)&h->kv.base, pool_bytes) != hipSuccess) return fail(MGEA_ENOMEM, "KV pool allocation failed");
         if (hipMemset(h->kv.base, 0, pool_bytes) != hipSuccess) return fail(MGEA_EHIP, "KV pool memset failed");
@@ -737,7 +792,7 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     drop_graphs(h);
     free_ws(h);
     void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv,
-                 h->samp_dev, h->err_flag};
+                 h->samp_dev, h->err_flag, h->arena_own};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;

@@ -43,7 +43,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // NT = 16-column tiles per workgroup (2 only for the LM head: 32 columns per workgroup halve the A bytes per output)
-template <int EPI, bool LN, int MT, int NT>
+// F16 (MGEA_DTYPE_F16 engines): W is stored as _Float16 fragments of v_mfma_f32_16x16x32_f16 (launch_tile_weights_f16: half the
+// bytes, one 16-byte load per lane and chunk), the fp32 activations are rounded to fp16 in registers after the load -- lane
+// (c, g) of the k-tiled layout already holds the 8 consecutive k (k0 + 8 g .. + 7) that instruction wants -- and ONE MFMA
+// replaces the eight 16x16x4 fp32 ones of a chunk; accumulation, LayerNorm statistics and every epilogue stay fp32.  With LN
+// the LayerNorm weight gamma multiplies the activations before the rounding (W stays the plain rounded matrix, so the model
+// is exactly "the reference with fp16-rounded matrices"): LN(x) W^T + b = rstd (sum_k (gamma_k x_k) W_nk - mean c1_n) + c2_n.
+template <int EPI, bool LN, int MT, int NT, bool F16>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
     // LDS row pitch of the partial tiles: + 4 floats, so that the 16 rows one ds_write_b128 of a wave touches do not
@@ -64,8 +70,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     // path of a ~6 us kernel.  Asking for every field here makes them ONE batch of loads and one wait.
     asm volatile("" :: "s"(a.A), "s"(a.W), "s"(a.bias), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.ln_c1), "s"(a.eps),
                        "s"(a.stats_in), "s"(a.n_part), "s"(a.part_cnt), "s"(a.out), "s"(a.ldo), "s"(a.stats_out), "s"(a.act), "s"(a.dbg), "s"(a.nw));
+    if (F16 && LN) asm volatile("" :: "s"(a.ln_g));
     if (EPI == EPI_QKV)
-        asm volatile("" :: "s"(a.pool.base), "s"(a.pool.H), "s"(a.pool.dh), "s"(a.pool.layer_stride), "s"(a.layer), "s"(a.page_table),
+        asm volatile("" :: "s"(a.pool.base), "s"(a.pool.H), "s"(a.pool.dh), "s"(a.pool.layer_stride), "s"(a.pool.f16), "s"(a.layer), "s"(a.page_table),
                            "s"(a.max_pages), "s"(a.ctx_len), "s"(a.lens), "s"(a.T), "s"(a.C));
     if (EPI == EPI_LOGITS) asm volatile("" :: "s"(a.pmax_val), "s"(a.pmax_idx));
     const int n_tiles = (a.N + COLS - 1) / COLS;
@@ -104,10 +111,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     const float* atile[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) atile[mt] = a.A + tiled_off(m0 + mt * 16, kbeg, a.K) + lane * 4;
+    // per (16-row tile, 32-wide chunk): 512 floats (two 1 KB halves h = 0, 1) or 512 halves (one 1 KB block)
     const float* wtile[NT];
+    const _Float16* wtile16[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        wtile[nt] = a.W + ((int64_t)((n0 >> 4) + nt) * (a.K >> 5) + (kbeg >> 5)) * 512 + lane * 4;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t blk = ((int64_t)((n0 >> 4) + nt) * (a.K >> 5) + (kbeg >> 5)) * 512;
+        wtile[nt] = a.W + blk + lane * 4;
+        wtile16[nt] = reinterpret_cast<const _Float16*>(a.W) + blk + lane * 8;
+    }
+    const float* gtile = (F16 && LN) ? a.ln_g + kbeg + 8 * g : nullptr;   // gamma of this lane's 8 k per chunk
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -115,21 +128,45 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wf[DEPTH][NT][2], af[DEPTH][MT][2];
+    float4 wf[DEPTH][NT][2], af[DEPTH][MT][2], gf[DEPTH][2];
+    h16x8 wh[DEPTH][NT];
     auto load_chunk = [&](int buf, int ch) {
-        const int ko = ch * 32;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            wf[buf][nt][0] = ld4(wtile[nt] + ch * 512);
-            wf[buf][nt][1] = ld4(wtile[nt] + ch * 512 + 256);
+            if (F16) {
+                wh[buf][nt] = *reinterpret_cast<const h16x8*>(wtile16[nt] + ch * 512);
+            } else {
+                wf[buf][nt][0] = ld4(wtile[nt] + ch * 512);
+                wf[buf][nt][1] = ld4(wtile[nt] + ch * 512 + 256);
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             af[buf][mt][0] = ld4(atile[mt] + ch * 2048);
             af[buf][mt][1] = ld4(atile[mt] + ch * 2048 + 256);
         }
+        if (F16 && LN) {
+            gf[buf][0] = ld4(gtile + ch * 32);
+            gf[buf][1] = ld4(gtile + ch * 32 + 4);
+        }
     };
     auto compute_chunk = [&](int buf) {
+        if (F16) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 x0 = af[buf][mt][0], x1 = af[buf][mt][1];
+                if (LN) {
+                    const float4 g0 = gf[buf][0], g1 = gf[buf][1];
+                    x0 = make_float4(x0.x * g0.x, x0.y * g0.y, x0.z * g0.z, x0.w * g0.w);
+                    x1 = make_float4(x1.x * g1.x, x1.y * g1.y, x1.z * g1.z, x1.w * g1.w);
+                }
+                const h16x8 x8 = to_h8(x0, x1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][nt], x8, acc[mt][nt], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -277,14 +314,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
                 const int page = pos >> 6, slot = pos & 63;
                 if (page < a.max_pages) {
                     const int phys = first ? e_phys : a.page_table[b * a.max_pages + page];
-                    const int64_t pf = a.pool.page_floats();
                     const int isv = n >= 2 * a.C;
                     const int nn = n - (isv ? 2 * a.C : a.C);
-                    const int hh = nn / a.pool.dh, d = nn % a.pool.dh;
-                    float* page_p = a.pool.base + a.layer * a.pool.layer_stride +
-                                    ((int64_t)(phys * 2 + isv) * a.pool.H + hh) * pf;
-                    if (isv) st4(page_p + slot * a.pool.dh + d, v);
-                    else     st4(page_p + ((d >> 2) * MGEA_KV_PAGE_TOKENS + slot) * 4, v);
+                    kv_store4(a.pool, a.layer, phys, isv, nn / a.pool.dh, slot, nn % a.pool.dh, v);
                 }
             }
         }
@@ -348,8 +380,13 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
     a.nw = nw;
     dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
     const size_t shmem = ((size_t)nw * 16 * MT * (16 * NT + 4) + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
-    if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1>), grid, block, shmem, st, a);
-    else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT>), grid, block, shmem, st, a);
+    if (a.w_f16) {
+        if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1, true>), grid, block, shmem, st, a);
+        else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT, true>), grid, block, shmem, st, a);
+    } else {
+        if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1, false>), grid, block, shmem, st, a);
+        else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT, false>), grid, block, shmem, st, a);
+    }
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -371,6 +408,7 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     while (ln && mt > 1 && nw * 64 < 16 * mt * 16) mt /= 2;   // the LN merge wants 16 lanes per tile row
     MGEA_REQUIRE((a.K / 32) % nw == 0 && nw <= 8, MGEA_EINVAL, "skinny gemm: bad wave count %d", nw);
     MGEA_REQUIRE(!ln || a.n_part <= 64, MGEA_EINVAL, "skinny gemm: more than 64 LayerNorm partials per row (%d)", a.n_part);
+    MGEA_REQUIRE(!(ln && a.w_f16) || a.ln_g, MGEA_EINVAL, "skinny gemm: the fp16 folded LayerNorm needs gamma (ln_g)");
     MGEA_REQUIRE(!ln || a.n_part % 2 == 0, MGEA_EINVAL, "skinny gemm: odd number of LayerNorm partials per row (%d)", a.n_part);
     MGEA_REQUIRE(!ln || nw * 64 >= 16 * mt * 16, MGEA_EINVAL,
                  "skinny gemm: the LayerNorm merge needs 16 lanes per tile row (K=%d, %d-row tiles, %d waves)", a.K, 16 * mt, nw);
@@ -427,7 +465,46 @@ int launch_tile_weights(const float* W, int N, int K, float* out, hipStream_t st
     return MGEA_OK;
 }
 
-// c1[n] = sum_k fl(gamma[k] * W[n,k]),  c2[n] = sum_k beta[k] * W[n,k] + bias[n]; one wave per row, fp64 sums
+// fp16 fragments: one thread per 16-byte group (8 halves) of the output
+__global__ __launch_bounds__(256) void tile_weights_f16_kernel(const float* __restrict__ W, int N, int K, _Float16* __restrict__ out, int64_t n_g8) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_g8) return;
+    const int64_t blk = o >> 6;            // (tile, chunk) block of 64 lanes
+    const int lane = (int)(o & 63), g = lane >> 4, c = lane & 15;
+    const int chunks = K >> 5;
+    const int64_t tile = blk / chunks;
+    const int kc = (int)(blk % chunks);
+    const int64_t n = tile * 16 + c;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (n < N) {
+        v0 = ld4(W + n * K + kc * 32 + 8 * g);
+        v1 = ld4(W + n * K + kc * 32 + 8 * g + 4);
+    }
+    *reinterpret_cast<h16x8*>(out + o * 8) = to_h8(v0, v1);
+}
+
+int launch_tile_weights_f16(const float* W, int N, int K, void* out, hipStream_t st) {
+    MGEA_REQUIRE(W && out && N >= 1 && K >= 32 && K % 32 == 0, MGEA_EINVAL, "tile_weights_f16: N=%d K=%d (K must be a multiple of 32)", N, K);
+    const int64_t n_g8 = wtile_floats(N, K) / 8;
+    hipLaunchKernelGGL(tile_weights_f16_kernel, dim3((unsigned)((n_g8 + 255) / 256)), dim3(256), 0, st, W, N, K, static_cast<_Float16*>(out), n_g8);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+__global__ __launch_bounds__(256) void round_f16_inplace_kernel(float* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = (float)(_Float16)x[i];
+}
+
+int launch_round_f16_inplace(float* x, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(round_f16_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// c1[n] = sum_k fl(gamma[k] * W[n,k]) (EXACT = 0: the fp32 products the tiled copy stores) or sum_k gamma[k] * W[n,k] (EXACT = 1:
+// gamma applied on the activation side),  c2[n] = sum_k beta[k] * W[n,k] + bias[n]; one wave per row, fp64 sums
+template <int EXACT>
 __global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
                                                               float* __restrict__ c1, float* __restrict__ c2) {
@@ -436,7 +513,7 @@ __global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __res
     double s1 = 0.0, s2 = 0.0;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(int64_t)n * K + k];
-        s1 += (double)(w * gamma[k]);
+        s1 += EXACT ? (double)w * (double)gamma[k] : (double)(w * gamma[k]);
         s2 += (double)w * (double)beta[k];
     }
 #pragma unroll
@@ -454,7 +531,15 @@ int launch_ln_fold(const float* W, const float* gamma, const float* beta, const 
                    float* c1, float* c2, hipStream_t st) {
     MGEA_REQUIRE(gamma && beta && c1 && c2, MGEA_EINVAL, "ln_fold: NULL argument");
     MGEA_TRY(launch_tile_weights(W, N, K, out, st, gamma));
-    hipLaunchKernelGGL(ln_fold_vectors_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, W, gamma, beta, bias, N, K, c1, c2);
+    hipLaunchKernelGGL(ln_fold_vectors_kernel<0>, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, W, gamma, beta, bias, N, K, c1, c2);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+int launch_ln_vectors(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, float* c1, float* c2,
+                      hipStream_t st) {
+    MGEA_REQUIRE(W && gamma && beta && c1 && c2, MGEA_EINVAL, "ln_vectors: NULL argument");
+    hipLaunchKernelGGL(ln_fold_vectors_kernel<1>, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, W, gamma, beta, bias, N, K, c1, c2);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(SkinnyArgs a) {
             if (n >= a.C) {
                 const int slot = e_pos & 63, phys = e_phys;
                 if (phys >= 0) {
-                    const int64_t pf = a.pool.page_floats();
+                    const int64_t pf = a.pool.page_elems();   // fp32 pages only (the launcher refuses an fp16 pool)
                     const int isv = n >= 2 * a.C;
                     const int nn = n - (isv ? 2 * a.C : a.C);
                     const int hh = nn / a.pool.dh, d = nn % a.pool.dh;
-                    float* page_p = a.pool.base + a.layer * a.pool.layer_stride + ((int64_t)(phys * 2 + isv) * a.pool.H + hh) * pf;
+                    float* page_p = static_cast<float*>(a.pool.base) + a.layer * a.pool.layer_stride + ((int64_t)(phys * 2 + isv) * a.pool.H + hh) * pf;
                     if (isv) page_p[slot * a.pool.dh + d] = v;
                     else     page_p[((d >> 2) * MGEA_KV_PAGE_TOKENS + slot) * 4 + (d & 3)] = v;
                 }
@@ -238,6 +238,7 @@ int launch_gemv(int epi, const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE(gemv_shape_ok(a.M, a.N, a.K), MGEA_EINVAL, "gemv: M=%d (1..2) N=%d K=%d (multiple of 256)", a.M, a.N, a.K);
     MGEA_REQUIRE(epi == EPI_LOGITS || a.N % 8 == 0, MGEA_EINVAL, "gemv: N=%d must be a multiple of 8", a.N);
     MGEA_REQUIRE(epi != EPI_QKV || (a.T == 1 && !a.lens), MGEA_EINVAL, "gemv: the QKV epilogue handles single-token decode steps only");
+    MGEA_REQUIRE(!a.w_f16 && !(epi == EPI_QKV && a.pool.f16), MGEA_EINVAL, "gemv: fp32 weights and KV pages only");
     MGEA_REQUIRE(!a.ln_g || (a.ln_b && a.K <= 1024), MGEA_EINVAL, "gemv: LayerNorm prologue needs beta and K <= 1024 (K=%d)", a.K);
     const int cw = gemv_cw(epi, a.N);
     switch (epi) {

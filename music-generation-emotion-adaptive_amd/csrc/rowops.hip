@@ -261,9 +261,7 @@ int launch_bias_res_ln(const float* P, int S, int64_t ps, int ldp, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// qkv epilogue + KV page scatter.  K page layout [dh/4][64 tokens][4] (token-major inside a
-// 16-byte d-chunk: the decode kernel's lane = token reads are 1 KiB contiguous per wave
-// instruction); V page layout [64 tokens][dh].
+// qkv epilogue + KV page scatter (page layouts: KvPool in common.h; fp32 or fp16 elements).
 __global__ __launch_bounds__(256) void qkv_scatter_kernel(const float* __restrict__ P, int S, int64_t ps, int ldp,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ qkv_out, KvPool pool, int layer,
@@ -277,9 +275,6 @@ __global__ __launch_bounds__(256) void qkv_scatter_kernel(const float* __restric
     const int page = pos >> 6, slot = pos & 63;
     const bool cache_ok = real && page < max_pages;
     const int phys = cache_ok ? page_table[b * max_pages + page] : 0;
-    const int64_t pf = pool.page_floats();
-    float* kpage = pool.base + layer * pool.layer_stride + (int64_t)(phys * 2 + 0) * pool.H * pf;
-    float* vpage = pool.base + layer * pool.layer_stride + (int64_t)(phys * 2 + 1) * pool.H * pf;
     const int nf4 = (3 * C) >> 2;
     for (int f = threadIdx.x; f < nf4; f += 256) {
         const int n = f * 4;
@@ -290,13 +285,8 @@ __global__ __launch_bounds__(256) void qkv_scatter_kernel(const float* __restric
         }
         st4(qkv_out + m * 3 * C + n, v);
         if (cache_ok && n >= C) {
-            if (n < 2 * C) {
-                const int hh = (n - C) / pool.dh, d = (n - C) % pool.dh;
-                st4(kpage + hh * pf + ((d >> 2) * MGEA_KV_PAGE_TOKENS + slot) * 4, v);
-            } else {
-                const int hh = (n - 2 * C) / pool.dh, d = (n - 2 * C) % pool.dh;
-                st4(vpage + hh * pf + slot * pool.dh + d, v);
-            }
+            const int isv = n >= 2 * C, nn = n - (isv ? 2 * C : C);
+            kv_store4(pool, layer, phys, isv, nn / pool.dh, slot, nn % pool.dh, v);
         }
     }
 }

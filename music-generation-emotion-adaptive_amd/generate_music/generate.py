@@ -87,10 +87,11 @@ class GPTWithKV:
     block_mode = "kv"
 
     def __init__(self, vocab_size, seq_len, d_model, n_head, n_layer, max_batch: int = 8,
-                 max_ctx: Optional[int] = None, device: str = _DEFAULT_DEVICE):
+                 max_ctx: Optional[int] = None, device: str = _DEFAULT_DEVICE, dtype: str = "f32"):
         self.vocab_size, self.seq_len, self.d_model = int(vocab_size), int(seq_len), int(d_model)
         self.n_head, self.n_layer = int(n_head), int(n_layer)
         self.max_batch, self.max_ctx, self.device = int(max_batch), max_ctx, device
+        self.dtype = dtype   # "f32" = the reference's arithmetic (parity mode); "f16" = fp16 matrices + KV (mgea.decoder)
         self.engine: Optional[DecoderEngine] = None
         self._epoch = -1
 
@@ -106,7 +107,7 @@ class GPTWithKV:
             self.engine.close()
         max_ctx = self.max_ctx if self.max_ctx is not None else max(self.seq_len, 1)
         self.engine = DecoderEngine(sd, n_head=self.n_head, max_batch=self.max_batch, max_ctx=max_ctx,
-                                    device=self.device, block_mode=self.block_mode)
+                                    device=self.device, block_mode=self.block_mode, dtype=self.dtype)
         return "<All keys matched successfully>"
 
     def eval(self):

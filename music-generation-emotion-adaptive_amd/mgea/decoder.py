@@ -68,12 +68,25 @@ def arena_layout(geometry: Dict[str, int], n_head: int = 8):
     return list(offs), total.value
 
 
+# training-checkpoint tensor-name suffixes of the matrices the fp16 mode stores in fp16 (everything else stays fp32)
+F16_ROUNDED_KEYS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight", "fc.weight",
+                    "attn.in_proj_weight", "attn.out_proj.weight", "mlp.0.weight", "mlp.2.weight", "head.weight")
+
+
 class DecoderEngine:
     """One native decoder handle on one GPU."""
 
     def __init__(self, state_dict: Optional[Dict], n_head: int = 8, max_batch: int = 64, max_ctx: Optional[int] = None,
                  device="cuda:0", block_mode: str = "kv", pos_mode: str = "reference", geometry: Optional[Dict] = None,
-                 arena: Optional[torch.Tensor] = None, ln_eps: float = 1e-5):
+                 arena: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, dtype: str = "f32"):
+        """dtype "f32": the parity mode (fp32 storage, exact-fp32 MFMA; bit-exact greedy ids against the reference).
+        dtype "f16": the perf mode of BASELINE configs[4] -- the five projection-matrix kinds and the KV pages are stored
+        in fp16 (half the bytes a decode step streams), accumulation / residual stream / LayerNorm / softmax / logits
+        stay fp32.  The model it serves is exactly the reference with those matrices rounded to fp16 (F16_ROUNDED_KEYS);
+        what differs from an fp32 run of THAT model is only activation and KV rounding (tests/test_gpu_f16.py)."""
+        if dtype not in ("f32", "f16"):
+            raise ValueError("decoder dtype must be 'f32' or 'f16'")
+        self.dtype = dtype
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -85,7 +98,7 @@ class DecoderEngine:
         self.max_ctx = int(max_ctx if max_ctx is not None else self.seq_len)
         self.cfg = DecoderConfig(vocab=self.vocab, seq_len=self.seq_len, d_model=self.d_model, n_head=self.n_head,
                                  n_layer=self.n_layer, d_ff=self.d_ff, max_batch=self.max_batch, max_ctx=self.max_ctx,
-                                 dtype=_lib.DTYPE_F32,
+                                 dtype=_lib.DTYPE_F16 if dtype == "f16" else _lib.DTYPE_F32,
                                  block_mode=_lib.BLOCK_PRELN_GELU if block_mode == "kv" else _lib.BLOCK_POSTLN_RELU,
                                  pos_mode=_lib.POS_REFERENCE if pos_mode == "reference" else _lib.POS_ABSOLUTE,
                                  ln_eps=ln_eps)

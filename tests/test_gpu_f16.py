@@ -1,0 +1,189 @@
+"""The decoder's fp16 storage mode (MGEA_DTYPE_F16; BASELINE configs[4] is quoted in fp16): projection matrices and KV pages in
+fp16, fp32 accumulation / residual stream / LayerNorm / softmax / logits.
+
+The reference has only fp32 (api_cache.py:30,204), so this mode cannot meet -- and does not claim -- the bit-exact bar; the f32
+mode is the parity mode.  What is checked here, as SURVEY §7 "Precision vs the parity bar" prescribes:
+  * the model served is EXACTLY the reference with its five matrix kinds rounded to fp16: the oracle runs on those rounded
+    weights upcast to fp32, and the engine is compared with it teacher-forced (same fed ids), so the measured difference is
+    only activation / KV rounding: per-step logit error and argmax-agreement rate, on Decoder-S and on 12L / 768d;
+  * BASELINE configs[4] as written runs: 12L / 768d, top-p 0.9, 2048 tokens through the captured step graph (size-independent
+    properties at full length + the oracle on a short prefix);
+  * everything structural still holds in this mode (row independence, determinism, page crossings, ragged prompts, EOS).
+"""
+import numpy as np
+import pytest
+import torch
+
+from mgea import synth
+
+pytestmark = pytest.mark.gpu
+
+# observed on MI355X: ~4e-3 (Decoder-S) / ~6e-3 (12L/768d) max |logit diff| over the teacher-forced runs below; fp16 has a 2^-11
+# relative step, the residual stream is O(10) and the logits are sums of 512-768 products, so O(1e-2) is the expected scale
+F16_LOGIT_TOL = 3e-2
+
+
+def rounded(sd):
+    """The model the fp16 engine serves: the five matrix kinds rounded to fp16 (RNE), everything else untouched."""
+    from mgea.decoder import F16_ROUNDED_KEYS
+    out = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.asarray(v)).float()
+        out[k] = t.half().float() if k.endswith(F16_ROUNDED_KEYS) else t
+    return out
+
+
+def teacher_forced(eng, ref, prompts, n_steps):
+    """Feed the engine the ORACLE's greedy ids step by step.  Returns (max |logit diff| over all steps and rows, argmax
+    agreement rate, mean over steps of the per-step max diff).  Every argmax disagreement must sit at a step where the
+    oracle's own top-2 gap is within twice that step's logit error (otherwise the argmax path itself would be wrong)."""
+    want, sl = ref.generate_greedy(prompts, n_steps, return_logits=True)
+    B, Tp = len(prompts), max(len(p) for p in prompts)
+    idx = torch.zeros(B, Tp, dtype=torch.long)
+    for b, p in enumerate(prompts):
+        idx[b, :len(p)] = torch.tensor(p)
+    lens = None if all(len(p) == Tp for p in prompts) else torch.tensor([len(p) for p in prompts])
+    eng.reset_and_prefill(idx, lens, want_logits=False, max_len=Tp + n_steps)
+    samp = eng.sampler(1.0, 1)
+    srt = sl.sort(-1).values
+    gap = srt[..., -1] - srt[..., -2]
+    worst, agree, diffs = 0.0, 0, []
+    for s in range(n_steps):
+        fed = torch.tensor([want[b][len(p) + s - 1] for b, p in enumerate(prompts)], dtype=torch.int32)
+        out, lg = eng.step(fed, samp, want_logits=True)
+        row_d = (lg.cpu() - sl[:, s]).abs().max(-1).values
+        diffs.append(float(row_d.max()))
+        worst = max(worst, diffs[-1])
+        o = out.cpu().tolist()
+        for b, p in enumerate(prompts):
+            if o[b] == want[b][len(p) + s]:
+                agree += 1
+            else:
+                assert float(gap[b, s]) <= 2 * float(row_d[b]) + 1e-6, \
+                    f"argmax differs at row {b} step {s} although the oracle's gap {float(gap[b, s]):.3e} exceeds twice the logit error {float(row_d[b]):.3e}"
+    return worst, agree / (B * n_steps), float(np.mean(diffs))
+
+
+def test_f16_decoder_s_teacher_forced_against_oracle_on_rounded_weights(golden):
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    g = golden("decoder_S")
+    seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
+    sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=4, max_ctx=256, dtype="f16")
+    ref = DecoderRef(rounded(sd), n_head)
+    prompts = [g[f"prompt{i}"].tolist() for i in range(4)]          # ragged lengths
+    worst, agree, mean_d = teacher_forced(eng, ref, prompts, 96)   # crosses a KV page
+    print(f"[f16] Decoder-S 4 rows x 96 teacher-forced steps vs oracle(fp16-rounded matrices): max |logit diff| {worst:.2e}, "
+          f"mean-of-step-max {mean_d:.2e}, argmax agreement {agree:.4f}")
+    assert worst < F16_LOGIT_TOL
+    assert agree >= 0.95
+    # and the mode is not a no-op: against the UNROUNDED model the fp32 engine is ~1e-5 away, this one is not
+    ref32 = DecoderRef(sd, n_head)
+    w32, *_ = teacher_forced(eng, ref32, prompts[:1], 8)
+    assert w32 > 1e-4
+
+
+def test_f16_decoder_l_teacher_forced_against_oracle_on_rounded_weights():
+    """BASELINE configs[4] geometry: 12L / 768d, 12 heads x 64."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    sd = synth.decoder_state_dict(77, 2000, 256, 768, 12)
+    eng = DecoderEngine(sd, n_head=12, max_batch=4, max_ctx=256, dtype="f16")
+    ref = DecoderRef(rounded(sd), 12)
+    prompts = [[1, 6, 17, 33, 34], [1, 10, 28], [5, 9, 2, 44, 7]]
+    worst, agree, mean_d = teacher_forced(eng, ref, prompts, 72)
+    print(f"[f16] 12L/768d 3 rows x 72 teacher-forced steps vs oracle(fp16-rounded matrices): max |logit diff| {worst:.2e}, "
+          f"mean-of-step-max {mean_d:.2e}, argmax agreement {agree:.4f}")
+    assert worst < F16_LOGIT_TOL
+    assert agree >= 0.95
+
+
+def test_f16_prefill_logits_against_oracle_on_rounded_weights(golden):
+    """Prefill through the fused path (<= 512 rows) and through the 128x128-tile path on the engine's rounded fp32 copy
+    (> 512 rows): both serve the same rounded model."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    g = golden("decoder_tiny8h")
+    seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
+    sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=16, max_ctx=seq_len, dtype="f16")
+    ref = DecoderRef(rounded(sd), n_head)
+    small = torch.from_numpy(synth.integers(3, "pf", (4, 20), 0, vocab))
+    big = torch.from_numpy(synth.integers(4, "pf", (16, 48), 0, vocab))            # 768 rows > 512: the big-M path
+    for idx, tol in ((small, F16_LOGIT_TOL), (big, 1e-3)):   # the big-M path is fp32 arithmetic on the rounded weights
+        got = eng.reset_and_prefill(idx).cpu()
+        want, _, _ = ref.forward(idx)
+        assert float((got - want).abs().max()) < tol, float((got - want).abs().max())
+    # decode after the big-M prefill reads fp16 pages written by the scatter kernel
+    samp = eng.sampler(1.0, 1)
+    _, cache, valid = ref.forward(big)
+    want, _, _ = ref.forward(big[:, -1:], cache, valid)
+    _, lg = eng.step(None, samp, want_logits=True)
+    assert float((lg.cpu() - want[:, -1]).abs().max()) < F16_LOGIT_TOL
+
+
+def test_f16_config4_as_written_2048_tokens_top_p_through_the_graph():
+    """BASELINE configs[4]: 12-layer / 768-dim decoder, top-p = 0.9 sampling, 2048-token generation, fp16, hipGraph-captured
+    decode step (here 8 of the 64 rows one GPU gets).  The oracle cannot follow 2043 sampled steps, so at full length the
+    checks are size-independent properties; the arithmetic of the same engine is pinned by the teacher-forced test above."""
+    from mgea.decoder import DecoderEngine
+    sd = synth.decoder_state_dict(5, 8324, 2048, 768, 12)
+    eng = DecoderEngine(sd, n_head=12, max_batch=8, max_ctx=2048, dtype="f16")
+    prompts = synth.integers(1, "p", (8, 5), 0, 8324).tolist()
+    n = 2048 - 5
+    a = eng.generate(prompts, n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    st = eng.stats()
+    assert st["graph_nodes"] == 5 * 12 + 2 and st["graph_replays"] == n        # the captured 62-launch step, replayed 2043 times
+    assert a.shape == (8, n) and int(a.min()) >= 0 and int(a.max()) < 8324
+    assert eng.context_lengths().cpu().tolist() == [2048] * 8                  # every row filled its 32 KV pages
+    b = eng.generate(prompts, n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    assert torch.equal(a, b)                                                   # same seed: bit-identical (no atomics)
+    c = eng.generate(prompts, n, temperature=1.0, top_k=None, top_p=0.9, seed=12).cpu()
+    assert not torch.equal(a, c) and eng.stats()["graph_instantiates"] == st["graph_instantiates"]
+    assert len(set(a[0].tolist())) > 100                                       # it really samples
+    sub = eng.generate([prompts[i] for i in (0, 3, 7)], n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    # rows are independent of the batch they run in as long as their (seed, row index) Philox stream is the same: row 0
+    assert torch.equal(sub[0], a[0])
+    # greedy at full length: deterministic and batch-composition independent for every row
+    g1 = eng.generate(prompts, n, top_k=1).cpu()
+    g2 = eng.generate([prompts[i] for i in (5, 2)], n, top_k=1).cpu()
+    assert torch.equal(g2[0], g1[5]) and torch.equal(g2[1], g1[2])
+
+
+def test_f16_structure_rows_eos_and_refresh(golden):
+    from mgea.decoder import DecoderEngine
+    g = golden("decoder_tiny8h")
+    seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
+    sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=40, max_ctx=seq_len, dtype="f16")
+    rs = np.random.RandomState(5)
+    prompts = [rs.randint(0, vocab, size=int(rs.randint(1, 8))).tolist() for _ in range(40)]
+    big = eng.generate(prompts, 20, top_k=1).cpu()
+    for i0 in range(0, 40, 8):
+        assert torch.equal(big[i0:i0 + 8], eng.generate(prompts[i0:i0 + 8], 20, top_k=1).cpu())
+    solo = eng.generate(prompts[:1], 20, top_k=1).cpu()          # one row: the MFMA path too (no gemv in this mode)
+    assert torch.equal(solo[0], big[0])
+    eos = int(big[0, 3])
+    out = eng.generate(prompts[:2], 20, top_k=1, eos_id=eos).cpu()
+    stop = big[0].tolist().index(eos) + 1
+    assert out[0, :stop].tolist() == big[0, :stop].tolist() and bool((out[0, stop:] == -1).all())
+    # refresh_weights follows an in-place arena rewrite in this mode as well (rounded copy + fp16 tiles rebuilt)
+    sd2 = synth.decoder_state_dict(seed + 1, vocab, seq_len, d_model, n_layer)
+    other = DecoderEngine(sd2, n_head=n_head, max_batch=4, max_ctx=seq_len, dtype="f16")
+    want = other.generate(prompts[:4], 20, top_k=1).cpu()
+    eng.arena.copy_(other.arena)
+    torch.cuda.synchronize()
+    eng.refresh_weights()
+    assert torch.equal(eng.generate(prompts[:4], 20, top_k=1).cpu(), want)
+
+
+def test_f16_geometry_limits():
+    from mgea.decoder import DecoderEngine
+    sd = synth.decoder_state_dict(21, 500, 64, 768, 2)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        DecoderEngine(sd, n_head=8, max_batch=2, max_ctx=64, dtype="f16")      # 768 / 8 = 96
+    with pytest.raises(RuntimeError):
+        DecoderEngine(sd, n_head=12, max_batch=2, max_ctx=64, dtype="f16", block_mode="twin")
+    with pytest.raises(ValueError):
+        DecoderEngine(sd, n_head=12, max_batch=2, max_ctx=64, dtype="bf16")
