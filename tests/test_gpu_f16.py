@@ -18,9 +18,10 @@ from mgea import synth
 
 pytestmark = pytest.mark.gpu
 
-# observed on MI355X: ~4e-3 (Decoder-S) / ~6e-3 (12L/768d) max |logit diff| over the teacher-forced runs below; fp16 has a 2^-11
-# relative step, the residual stream is O(10) and the logits are sums of 512-768 products, so O(1e-2) is the expected scale
-F16_LOGIT_TOL = 3e-2
+# observed on MI355X (gpurun_out/r2_t3.log): max |logit diff| 9.9e-4 (Decoder-S, 4 rows x 96 steps) and 1.3e-3 (12L/768d, 3 rows x
+# 72 steps) with 100 % argmax agreement; fp16 has a 2^-11 relative step and the logits are sums of 512-768 products of O(1)
+# activations, so O(1e-3) is the expected scale.  The bound leaves a factor ~8 for other weights / longer contexts.
+F16_LOGIT_TOL = 1e-2
 
 
 def rounded(sd):
@@ -107,7 +108,7 @@ def test_f16_prefill_logits_against_oracle_on_rounded_weights(golden):
     g = golden("decoder_tiny8h")
     seed, vocab, seq_len, d_model, n_head, n_layer = (int(x) for x in g["cfg"])
     sd = synth.decoder_state_dict(seed, vocab, seq_len, d_model, n_layer)
-    eng = DecoderEngine(sd, n_head=n_head, max_batch=16, max_ctx=seq_len, dtype="f16")
+    eng = DecoderEngine(sd, n_head=n_head, max_batch=16, max_ctx=seq_len + 8, dtype="f16")   # room for decode steps after a full-table prefill
     ref = DecoderRef(rounded(sd), n_head)
     small = torch.from_numpy(synth.integers(3, "pf", (4, 20), 0, vocab))
     big = torch.from_numpy(synth.integers(4, "pf", (16, 48), 0, vocab))            # 768 rows > 512: the big-M path
