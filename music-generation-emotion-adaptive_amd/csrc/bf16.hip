@@ -42,14 +42,17 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2 };
 
-// erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, one v_exp + 5 fma): the
-// result is rounded to bf16 (2^-9) anyway; libm erff costs ~3x more VALU per element.
+// erf-GELU for bf16 outputs: erf from Abramowitz & Stegun 7.1.25 (|error| < 2.5e-5, far below the 2^-9 rounding of the bf16
+// result), t = 1 / (1 + p z) by v_rcp_f32 and exp(-z^2) by one v_exp_f32 (2^x): 12 VALU instructions per element.  The
+// 7.1.26 form with a full-precision division and libm-style exp cost ~40, i.e. ~14 us of a 40 us FC1 tile round.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = 1.0f / (1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    return 0.5f * fmaf(ax, erf_abs, x);      // 0.5 x (1 + sign(x) erf|.|) = 0.5 (x + |x| erf|.|)
 }
 
 template <int EPI>
@@ -294,6 +297,218 @@ __global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 of C per wave), the phase-interleaved structure of the
+// CDNA4 GEMM playbook (cdna_hip_programming.md T3+T4, "The 256^2 8-phase template"), written out from its rules:
+//
+//   * a K-tile is consumed in 4 PHASES of 16 MFMAs (one 64 x 32 quadrant of the wave's C over the whole BK = 64).  A phase is
+//     [L-segment: ds_read the fragments this phase's MFMAs need, issue 2 global_load_lds (this wave's share of one
+//      128-row half-tile of a LATER K-tile), wait for the reads] s_barrier [C-segment: 16 MFMAs] s_barrier.
+//   * waves 4-7 (the second wave of every SIMD) run ONE BARRIER LATER than waves 0-3: in every barrier-to-barrier interval
+//     one wave of each SIMD is in its C-segment (matrix pipe) and the other in its L-segment (LDS + address VALU + DMA
+//     issue) -- instead of both reading, then both fighting for the matrix pipe.
+//   * operands go HBM/L2 -> LDS by LDS-DMA (no staging registers, no ds_write), two 64 KB stages; the loads of a tile are
+//     issued 5-8 phases before its first read and are waited for with a COUNTED vmcnt once per K-tile (4 younger DMAs stay
+//     in flight across it); raw s_barrier only (a __syncthreads() would drain the DMA queue).
+//
+// Hazards, by construction (u = K-tile, stage = u & 1, phases q = 4u + p; L(q) / C(q) of waves 0-3 are intervals 2q / 2q+1,
+// of waves 4-7 intervals 2q+1 / 2q+2):
+//   reads  : p0 reads B(j=0) + A(i=0), p1 B(j=1), p2 A(i=1), p3 nothing (B(j=0) stays in registers); every ds_read is
+//            complete (lgkmcnt(0)) before the barrier that ends its L-segment.  So tile u's B halves are last read in
+//            interval 2(4u+1)+1 and its A halves in interval 2(4u+2)+1.
+//   WAR    : stage u & 1 is refilled with tile u+2: B-half 0 issued in phase 4u+2 (first interval 2(4u+2) > 2(4u+1)+1),
+//            A-half 0 in phase 4u+3 (2(4u+3) > 2(4u+2)+1), B-half 1 / A-half 1 in phases 4(u+1), 4(u+1)+1.
+//   RAW    : tile u+1 is first read in interval 2*4(u+1) = 8u+8.  Its last DMA (A-half 1) is issued in phase 4u+1; every wave
+//            waits until ITS DMAs of tile u+1 have landed -- vmcnt(4): only the two half-tiles issued in phases 4u+2, 4u+3
+//            may still be in flight -- at the end of interval 8u+7 (waves 0-3: end of C(4u+3); waves 4-7: end of L(4u+3)),
+//            and the barrier that ends that interval publishes them to every wave.
+// One 1 KiB LDS-DMA piece (64 lanes x 16 B, LDS destination = wave-uniform byte address + 16 * lane) issued from inline
+// asm, so that hipcc does not see it: seen through the builtin, ROCm 7.2 puts an s_waitcnt vmcnt(0) in front of the next
+// ds_read of every phase (it cannot tell which LDS bytes a pending DMA writes) and the pipeline drains.  Hidden, none of the
+// compiler's waits refer to it; every wait for these pieces is one of the hand-counted vmcnt below (this kernel has no other
+// vector-memory instruction between its prologue and its epilogue).  M0 is compiler-reserved: saved and restored in the same
+// statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;     // in 16-byte chunks: A tile, then the W tile
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [2][STAGE] = 128 KB; all LDS in this one array
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;               // wm = 1: the late group
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile runs (speed only)
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int KT = K >> 6;
+
+    // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
+    // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
+    const int lr = lane >> 3, lch = (lane & 7) ^ lr;
+    const bf16_t* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
+            ra = ra < M ? ra : M - 1;
+            src[hf][i] = A + (int64_t)ra * lda + lch * 8;
+            int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
+            rw = rw < N ? rw : N - 1;
+            src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
+        }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;   // LDS byte address of the ring
+    auto issue_half = [&](int hid, int kt) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
+        const int stage = kt & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
+            const unsigned dst = lds_base + (unsigned)(stage * STAGE + (hid >= 2 ? SA : 0) + row0 * 8) * 16u;
+            glds16_hidden(src[hid][i] + kt * 64, dst);
+        }
+    };
+
+    f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tile 0 whole, the first two half-tiles of tile 1 (the steady state issues W0 / A0 of tile u+2 in phases
+    // 4u+2 / 4u+3 and W1 / A1 of tile u+1 in phases 4u / 4u+1)
+    issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
+    if (KT > 1) {
+        issue_half(2, 1); issue_half(0, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
+
+    bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
+    for (int u = 0; u < KT; ++u) {
+        const float4* sb = lds + (u & 1) * STAGE;
+        const float4* sa = sb + (wm * 128) * 8;
+        const float4* sw = sb + SA + (wn * 64) * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // ---------------- L-segment
+            if (p == 0 || p == 1) {      // W fragments of the 32-column half j = p
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                        if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                    }
+            }
+            if (p == 0 || p == 2) {      // A fragments of the 64-row half i = p / 2
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float4 v = sa[(((p >> 1) * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                        af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p == 0 && u + 1 < KT) issue_half(3, u + 1);
+            if (p == 1 && u + 1 < KT) issue_half(1, u + 1);
+            if (p == 2 && u + 2 < KT) issue_half(2, u + 2);
+            if (p == 3 && u + 2 < KT) issue_half(0, u + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
+            if (p == 3 && wm == 1) {     // the late group confirms tile u+1 at the end of its L(4u+3) ...
+                if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- C-segment: quadrant (i, j) = (0,0) (0,1) (1,1) (1,0)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int i = p >> 1, j = (p == 1 || p == 2) ? 1 : 0;
+                        const bf16x8 wv = j ? bf1[n][ks] : bf0[n][ks];
+                        acc[j * 2 + n][i * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[j * 2 + n][i * 4 + m], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
+                if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
+
+    // Epilogue through LDS (the operand stages are free now), as in gemm_bf16_glds_kernel: bias / GELU in registers, the tile
+    // staged as [256][BN] bf16 and streamed out as whole rows, 16 bytes per lane; the residual is added on the way out.
+    constexpr int PITCH = BN * 2 + 16;
+    unsigned char* sC = reinterpret_cast<unsigned char*>(lds);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int lrow = wm * 128 + m * 16 + c;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int lcol = wn * 64 + n * 16 + 4 * g;
+            float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+            if (bias && n0 + lcol < N) v = add4(v, ld4(bias + n0 + lcol));
+            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+            *reinterpret_cast<bf16x4*>(sC + lrow * PITCH + lcol * 2) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 512; ++i) {
+        const int id = tid + i * 512, lrow = id / CPR, ch = id % CPR;
+        const int row = m0 + lrow, col = n0 + ch * 8;
+        if (row < M && col < N) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + lrow * PITCH + ch * 16);
+            if (EPI == BEPI_BIAS_RES) {
+                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
+            }
+            *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+        }
+    }
+}
+
+template <int EPI>
+static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
+                     int N, int K, hipStream_t st) {
+    constexpr size_t ring = 2 * (256 + 256) * 128, stage_c = (size_t)256 * (256 * 2 + 16);
+    const size_t shmem = ring > stage_c ? ring : stage_c;   // 132 KB of the 160 KB LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(tm * tn), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
 template <int EPI, int NT, int WMW>
 static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
                        int ldc, int M, int N, int K, hipStream_t st) {
@@ -326,6 +541,8 @@ static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, 
     if (force == 3) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
+    if (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256))   // the phase-interleaved 256 x 256 kernel (also for N = 768: 384 tiles)
+        return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
 }

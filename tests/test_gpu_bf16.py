@@ -35,6 +35,31 @@ def test_gemm_bf16(M, N, K, mode):
     assert float((err / (want.abs() + 1.0)).max()) < 6e-3        # bf16 output rounding (2^-9 relative) + accumulation
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 512, 64), (768, 768, 3072), (2048, 2304, 768), (1300, 3072, 768)])
+@pytest.mark.parametrize("mode", ["bias", "gelu", "res"])
+def test_gemm_bf16_phase_interleaved_kernel(M, N, K, mode, monkeypatch):
+    """The 256 x 256 phase-interleaved kernel (LDS-DMA issued from inline asm, hand-counted vmcnt, two wave groups one
+    barrier apart) forced on shapes that cover one K-tile, two, many, ragged M and every epilogue; the engine picks it by
+    itself only for the big DistilBERT GEMMs.  Every output element is checked against fp64 math on the same bf16 inputs,
+    twice (a race between DMA and ds_read would show up as rare wrong tiles, not as a rounding-sized error)."""
+    from mgea import ops
+    monkeypatch.setenv("MGEA_BF16_GEMM_TILE", "4")
+    a = rnd(M, K, seed=11).bfloat16()
+    w = rnd(N, K, seed=12, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=13)
+    r = rnd(M, N, seed=14).bfloat16()
+    want = a.double() @ w.double().t() + b.double()
+    if mode == "gelu":
+        want = torch.nn.functional.gelu(want)
+    if mode == "res":
+        want = want + r.double()
+    ac, wc, bc, rc = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+    for _ in range(2):
+        got = ops.gemm_bf16(ac, wc, bc, rc if mode == "res" else None, gelu=(mode == "gelu")).cpu()
+        err = (got.double() - want).abs()
+        assert float((err / (want.abs() + 1.0)).max()) < 6e-3
+
+
 def test_layernorm_bf16():
     from mgea import ops
     x, w, b = rnd(300, 768, seed=1, scale=3.0).bfloat16(), rnd(768, seed=2) + 1.0, rnd(768, seed=3)
