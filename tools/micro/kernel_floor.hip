@@ -1,0 +1,88 @@
+// What does one DEPENDENT kernel of a captured decode-step graph cost on MI355X, by ingredient?  The decode step at B <= 64 is
+// a chain of 32 kernels of ~5.5 us each whatever the batch (tools/decode_batch_sweep.py): this program times chains of 64
+// kernels replayed from a hipGraph, each variant adding one ingredient of the real skinny-GEMM kernels:
+//   empty      : 256 workgroups x 512 threads, no memory access
+//   args       : reads a 256-byte by-value argument struct (scalar loads from the kernarg segment), one store per workgroup
+//   args_pre   : the same fields as plain scalar arguments (eligible for kernarg preload when built with
+//                -mllvm -amdgpu-kernarg-preload-count=16)
+//   load       : args + every lane loads 2 x 16 B of the PREVIOUS kernel's output (another CU wrote it) and stores 16 B
+//   load_lds   : load + partial tiles through LDS and a workgroup barrier (the split-K reduction of the skinny GEMM)
+//   load2      : load_lds + a second, dependent load round trip (page table -> page, or statistics -> operands)
+// build: hipcc -O3 --offload-arch=gfx950 [-mllvm -amdgpu-kernarg-preload-count=16] tools/micro/kernel_floor.hip -o tools/micro/kernel_floor
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Args { const float* in; float* out; const int* idx; int n; int pad[57]; };   // 256 bytes like SkinnyArgs
+
+__global__ __launch_bounds__(512) void k_empty() {}
+
+__global__ __launch_bounds__(512) void k_args(Args a) {
+    if (threadIdx.x == 0) a.out[blockIdx.x * 2048] = (float)(a.n + a.pad[56]);
+}
+
+__global__ __launch_bounds__(512) void k_args_pre(const float* in, float* out, const int* idx, int n, int p56) {
+    if (threadIdx.x == 0) out[blockIdx.x * 2048] = (float)(n + p56);
+}
+
+template <int MODE>   // 0 load, 1 load + LDS reduce, 2 + dependent second round trip
+__global__ __launch_bounds__(512) void k_load(Args a) {
+    extern __shared__ float red[];
+    const int t = threadIdx.x, b = blockIdx.x;
+    int base = b;
+    if (MODE == 2) base = a.idx[b];                      // dependent hop (written by nobody in the chain: L2 / MALL resident)
+    const float4* src = reinterpret_cast<const float4*>(a.in) + (size_t)base * 1024 + t;
+    float4 x = src[0], y = src[512];
+    float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    if (MODE >= 1) {
+        reinterpret_cast<float4*>(red)[t] = v;
+        __syncthreads();
+        if (t < 128) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const float4 p = reinterpret_cast<float4*>(red)[t + 128 * w]; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+            reinterpret_cast<float4*>(a.out)[(size_t)b * 1024 + t] = s;
+        }
+    } else if (t < 128) {
+        reinterpret_cast<float4*>(a.out)[(size_t)b * 1024 + t] = v;
+    }
+}
+
+int main(int argc, char** argv) {
+    const int NB = argc > 1 ? atoi(argv[1]) : 256, CH = 64, REP = 50;
+    float *bufA, *bufB; int* idx;
+    CK(hipMalloc(&bufA, (size_t)NB * 1024 * 16 * 2)); CK(hipMalloc(&bufB, (size_t)NB * 1024 * 16 * 2)); CK(hipMalloc(&idx, NB * 4));
+    CK(hipMemset(bufA, 0, (size_t)NB * 1024 * 16 * 2)); CK(hipMemset(bufB, 0, (size_t)NB * 1024 * 16 * 2));
+    int* h = (int*)malloc(NB * 4); for (int i = 0; i < NB; ++i) h[i] = (i * 37) % NB; CK(hipMemcpy(idx, h, NB * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const char* names[] = {"empty", "args", "args_pre", "load", "load_lds", "load2"};
+    for (int v = 0; v < 6; ++v) {
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < CH; ++i) {
+            Args a{}; a.in = (i & 1) ? bufB : bufA; a.out = (i & 1) ? bufA : bufB; a.idx = idx; a.n = i;
+            switch (v) {
+                case 0: hipLaunchKernelGGL(k_empty, dim3(NB), dim3(512), 0, st); break;
+                case 1: hipLaunchKernelGGL(k_args, dim3(NB), dim3(512), 0, st, a); break;
+                case 2: hipLaunchKernelGGL(k_args_pre, dim3(NB), dim3(512), 0, st, a.in, a.out, a.idx, a.n, 0); break;
+                case 3: hipLaunchKernelGGL(k_load<0>, dim3(NB), dim3(512), 0, st, a); break;
+                case 4: hipLaunchKernelGGL(k_load<1>, dim3(NB), dim3(512), 8192, st, a); break;
+                case 5: hipLaunchKernelGGL(k_load<2>, dim3(NB), dim3(512), 8192, st, a); break;
+            }
+        }
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < REP; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-9s %4d workgroups: %6.2f us per dependent kernel\n", names[v], NB, ms * 1e3 / (REP * CH));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    }
+    return 0;
+}
