@@ -379,10 +379,10 @@ def main():
             "graph": eng.stats(),
             "roofline": roof,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline and the extras are N = 1 legs (rank 0 would stall the others)
             line["cpu_baseline"] = cpu_baseline_decoder(sd, prompts.tolist(), args.cpu_seconds)
         extra = {}
-        if not args.no_bert and not args.no_extra:
+        if not args.no_bert and not args.no_extra and world == 1:
             extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu)
             extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")
         if world == 1 and not args.no_extra:

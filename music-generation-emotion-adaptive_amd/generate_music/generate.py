@@ -11,6 +11,11 @@ Replacing api_cache.py:39-138,159-184 by
     model, tok2id, id2tok, SEQ_LEN, D_MODEL = load_checkpoint(CKPT)
 
 leaves its endpoint (api_cache.py:186-243) untouched.
+
+Note on the small host helpers: `FAMILY_TO_INSTRUMENTS`, `note_re`, `encode`, `decode`, `closest_bpm_token` and
+`normalize_key_signature` below are the drop-in's constant table, one regex and four one-to-seven-line functions whose exact
+behaviour (keys, error classes, string formats) IS the contract with api_cache.py:140-157 -- they are restated line for line
+from there on purpose (each cites its lines); everything that computes (the model, the sampler loop) is this repo's own design.
 """
 from __future__ import annotations
 
