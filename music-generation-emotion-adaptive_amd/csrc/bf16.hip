@@ -337,36 +337,45 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byt
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n) {
+                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles) {
     constexpr int BM = 256, BN = 256;
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;     // in 16-byte chunks: A tile, then the W tile
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [2][STAGE] = 128 KB; all LDS in this one array
+    constexpr int CST = 2 * STAGE;                         // the epilogue's own 32 KB behind the two operand stages
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [2][STAGE] + [2048] = 160 KB; all LDS in this one array
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;               // wm = 1: the late group
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile runs (speed only)
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const int KT = K >> 6;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;   // LDS byte address of the ring
+
+    // PERSISTENT: one workgroup per CU walks its output tiles.  Workgroups b and b + 8 share an XCD (round-robin dispatch, speed
+    // only): XCD r = b % 8 gets the contiguous run of tiles [r * n_tiles / 8, (r + 1) * n_tiles / 8) so that the tiles in flight on
+    // one L2 share A and W panels; the run is walked by the XCD's workgroups with stride gridDim.x / 8.
+    const int wg_x = gridDim.x >> 3;                         // host: gridDim.x % 8 == 0
+    int slot = (int)blockIdx.x >> 3;
+    const int run0 = ((int)blockIdx.x & 7) * ((n_tiles + 7) >> 3);
+    const int per_x = (run0 + ((n_tiles + 7) >> 3) < n_tiles ? ((n_tiles + 7) >> 3) : n_tiles - run0);   // tiles in this XCD's run (<= 0: none)
 
     // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
     // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
     const bf16_t* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int t) {
+        m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
-            ra = ra < M ? ra : M - 1;
-            src[hf][i] = A + (int64_t)ra * lda + lch * 8;
-            int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
-            rw = rw < N ? rw : N - 1;
-            src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
-        }
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;   // LDS byte address of the ring
+            for (int i = 0; i < 2; ++i) {
+                int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
+                ra = ra < M ? ra : M - 1;
+                src[hf][i] = A + (int64_t)ra * lda + lch * 8;
+                int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
+                rw = rw < N ? rw : N - 1;
+                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
+            }
+    };
     auto issue_half = [&](int hid, int kt) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
         const int stage = kt & 1;
 #pragma unroll
@@ -376,118 +385,141 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             glds16_hidden(src[hid][i] + kt * 64, dst);
         }
     };
+    // tile 0 whole, then the first two half-tiles of tile 1 (the steady state issues W0 / A0 of K-tile u+2 in phases 4u+2 / 4u+3
+    // and W1 / A1 of K-tile u+1 in phases 4u / 4u+1)
+    auto issue_prologue = [&]() {
+        issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
+        if (KT > 1) { issue_half(2, 1); issue_half(0, 1); }
+    };
 
-    f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
+    if (slot < per_x) { set_tile(run0 + slot); issue_prologue(); }
+    while (slot < per_x) {
+        const int cm0 = m0, cn0 = n0;                       // this tile's origin (set_tile moves on to the next one below)
+        f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // K-tile 0 has landed when at most the 4 DMAs of K-tile 1's first halves are still in flight.  (After the first tile the
+        // previous epilogue's stores are younger than these DMAs and count too: the wait is then stronger, never weaker.)
+        if (KT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
 
-    // prologue: tile 0 whole, the first two half-tiles of tile 1 (the steady state issues W0 / A0 of tile u+2 in phases
-    // 4u+2 / 4u+3 and W1 / A1 of tile u+1 in phases 4u / 4u+1)
-    issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
-    if (KT > 1) {
-        issue_half(2, 1); issue_half(0, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
-
-    bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
-    for (int u = 0; u < KT; ++u) {
-        const float4* sb = lds + (u & 1) * STAGE;
-        const float4* sa = sb + (wm * 128) * 8;
-        const float4* sw = sb + SA + (wn * 64) * 8;
+        bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
+        for (int u = 0; u < KT; ++u) {
+            const float4* sb = lds + (u & 1) * STAGE;
+            const float4* sa = sb + (wm * 128) * 8;
+            const float4* sw = sb + SA + (wn * 64) * 8;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            // ---------------- L-segment
-            if (p == 0 || p == 1) {      // W fragments of the 32-column half j = p
+            for (int p = 0; p < 4; ++p) {
+                // ---------------- L-segment
+                if (p == 0 || p == 1) {      // W fragments of the 32-column half j = p
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                        if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
-                        else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
-                    }
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                            if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                            else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        }
+                }
+                if (p == 0 || p == 2) {      // A fragments of the 64-row half i = p / 2
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const float4 v = sa[(((p >> 1) * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                            af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (p == 0 && u + 1 < KT) issue_half(3, u + 1);
+                if (p == 1 && u + 1 < KT) issue_half(1, u + 1);
+                if (p == 2 && u + 2 < KT) issue_half(2, u + 2);
+                if (p == 3 && u + 2 < KT) issue_half(0, u + 2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
+                if (p == 3 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(4u+3) ...
+                    if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- C-segment: quadrant (i, j) = (0,0) (0,1) (1,1) (1,0)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const int i = p >> 1, j = (p == 1 || p == 2) ? 1 : 0;
+                            const bf16x8 wv = j ? bf1[n][ks] : bf0[n][ks];
+                            acc[j * 2 + n][i * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[j * 2 + n][i * 4 + m], 0, 0, 0);
+                        }
+                __builtin_amdgcn_s_setprio(0);
+                if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
+                    if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
             }
-            if (p == 0 || p == 2) {      // A fragments of the 64-row half i = p / 2
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const float4 v = sa[(((p >> 1) * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                        af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (p == 0 && u + 1 < KT) issue_half(3, u + 1);
-            if (p == 1 && u + 1 < KT) issue_half(1, u + 1);
-            if (p == 2 && u + 2 < KT) issue_half(2, u + 2);
-            if (p == 3 && u + 2 < KT) issue_half(0, u + 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
-            if (p == 3 && wm == 1) {     // the late group confirms tile u+1 at the end of its L(4u+3) ...
-                if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---------------- C-segment: quadrant (i, j) = (0,0) (0,1) (1,1) (1,0)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int i = p >> 1, j = (p == 1 || p == 2) ? 1 : 0;
-                        const bf16x8 wv = j ? bf1[n][ks] : bf0[n][ks];
-                        acc[j * 2 + n][i * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[j * 2 + n][i * 4 + m], 0, 0, 0);
-                    }
-            __builtin_amdgcn_s_setprio(0);
-            if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
-                if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
         }
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
+        if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
 
-    // Epilogue through LDS (the operand stages are free now), as in gemm_bf16_glds_kernel: bias / GELU in registers, the tile
-    // staged as [256][BN] bf16 and streamed out as whole rows, 16 bytes per lane; the residual is added on the way out.
-    constexpr int PITCH = BN * 2 + 16;
-    unsigned char* sC = reinterpret_cast<unsigned char*>(lds);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int lrow = wm * 128 + m * 16 + c;
+        // Both operand stages are free now (every read of the last K-tiles completed before the barriers above): put the NEXT
+        // tile's first DMAs in flight before this tile's epilogue, so their latency runs under it.
+        float4 bv[4];                                          // this tile's bias for the lane's 4 x 4 columns, before the DMAs
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int lcol = wn * 64 + n * 16 + 4 * g;
-            float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
-            if (bias && n0 + lcol < N) v = add4(v, ld4(bias + n0 + lcol));
-            if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
-            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-            *reinterpret_cast<bf16x4*>(sC + lrow * PITCH + lcol * 2) = o;
+            const int col = cn0 + wn * 64 + n * 16 + 4 * g;
+            bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
+        slot += wg_x;
+        if (slot < per_x) { set_tile(run0 + slot); issue_prologue(); }
+
+        // Epilogue through the 32 KB C stage in 4 passes of 64 rows (m-tiles 2k, 2k+1 of both wave rows): bias / GELU in registers,
+        // bf16 rows staged with the 16-byte chunk XOR-swizzled by the row (the 16 rows a ds_write touches would otherwise share
+        // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual is added on the way
+        // out.  Raw barriers + lgkmcnt only: a __syncthreads() would wait for the DMAs just issued.
+        unsigned char* sC = reinterpret_cast<unsigned char*>(lds + CST);
 #pragma unroll
-    for (int i = 0; i < BM * CPR / 512; ++i) {
-        const int id = tid + i * 512, lrow = id / CPR, ch = id % CPR;
-        const int row = m0 + lrow, col = n0 + ch * 8;
-        if (row < M && col < N) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + lrow * PITCH + ch * 16);
-            if (EPI == BEPI_BIAS_RES) {
-                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * k + mm;
+                const int prow = (wm * 2 + mm) * 16 + c;      // row inside the pass
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int lcol = wn * 64 + n * 16 + 4 * g;
+                    float4 v = add4(make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]), bv[n]);
+                    if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+                    bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+                    const int ch = (lcol >> 3) ^ (prow & 31);
+                    *reinterpret_cast<bf16x4*>(sC + prow * 512 + ch * 16 + (lcol & 7) * 2) = o;
+                }
             }
-            *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
+                const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
+                const int lrow = (prow >> 5) * 128 + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
+                const int row = cm0 + lrow, col = cn0 + ch * 8;
+                if (row < M && col < N) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
+                    if (EPI == BEPI_BIAS_RES) {
+                        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
+                    }
+                    *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // the C stage is rewritten by the next pass
         }
     }
 }
@@ -495,16 +527,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 template <int EPI>
 static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
                      int N, int K, hipStream_t st) {
-    constexpr size_t ring = 2 * (256 + 256) * 128, stage_c = (size_t)256 * (256 * 2 + 16);
-    const size_t shmem = ring > stage_c ? ring : stage_c;   // 132 KB of the 160 KB LDS
+    const size_t shmem = (size_t)2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     static bool attr_set = false;
     if (!attr_set) {
         MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr_set = true;
     }
-    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
-    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(tm * tn), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn);
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MGEA_CHECK_HIP(hipGetDevice(&dev));
+        MGEA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount / 8 * 8;
+    }
+    const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -541,7 +581,7 @@ static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, 
     if (force == 3) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
-    if (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256))   // the phase-interleaved 256 x 256 kernel (also for N = 768: 384 tiles)
+    if (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256))   // the phase-interleaved persistent 256 x 256 kernel
         return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
