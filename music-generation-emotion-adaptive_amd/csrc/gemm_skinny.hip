@@ -49,7 +49,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 // replaces the eight 16x16x4 fp32 ones of a chunk; accumulation, LayerNorm statistics and every epilogue stay fp32.  With LN
 // the LayerNorm weight gamma multiplies the activations before the rounding (W stays the plain rounded matrix, so the model
 // is exactly "the reference with fp16-rounded matrices"): LN(x) W^T + b = rstd (sum_k (gamma_k x_k) W_nk - mean c1_n) + c2_n.
-template <int EPI, bool LN, int MT, int NT, bool F16>
+// NCH > 0 (the decode shapes of an engine: K = 32 * 8 * NCH): the workgroup has exactly 8 waves of NCH k-chunks each, all of them
+// requested up front (no refill loop, no per-chunk branches, no runtime division, no debug timestamps): tools/micro/kernel_floor.hip
+// shows that a kernel with this memory shape, LDS reduction, read-modify-write epilogue and MFMA chain costs ~3.0 us in a graph
+// chain where the generic instruction stream (NCH = 0: any K, any wave count) took 3.9.  Same chunks per wave, same MFMA order,
+// same wave-order reduction: bit-identical results.
+template <int EPI, bool LN, int MT, int NT, bool F16, int NCH>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
     // LDS row pitch of the partial tiles: + 4 floats, so that the 16 rows one ds_write_b128 of a wave touches do not
@@ -57,9 +62,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     constexpr int PITCH = COLS + 4;
     // k-chunks (32 wide) a wave keeps in flight.  Measured (tools/skinny_phases.py): deeper (4, 8) does not
     // help -- a CU's vector memory path sustains only ~40-60 GB/s of L2 hits however many loads are queued
-    constexpr int DEPTH = (MT * NT == 1) ? 4 : 2;
+    constexpr int DEPTH = NCH ? NCH : ((MT * NT == 1) ? 4 : 2);
     extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][PITCH] (+ LN: mean and rstd of the ROWS rows)
-    const int NW = a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
+    const int NW = NCH ? 8 : a.nw;   // = blockDim.x / 64, passed as an argument: blockDim comes from the dispatch packet, one more cold scalar load
     float* s_mean = red + NW * ROWS * PITCH;          // all LDS in ONE array (16-B aligned carve)
     float* s_rstd = s_mean + ROWS;
 
@@ -81,15 +86,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // tools/skinny_phases.py phase timing (dbg bit 20): 100 MHz timestamps of workgroup phases, written behind
     // the statistics in stats_out; the extra waits it inserts are only there in that mode
-    long long* ts = (a.dbg & (1 << 20)) ? reinterpret_cast<long long*>(a.stats_out + 64 * (a.N >> 4) * 2) +
-                                              (blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    long long* ts = (!NCH && (a.dbg & (1 << 20))) ? reinterpret_cast<long long*>(a.stats_out + 64 * (a.N >> 4) * 2) +
+                                                        (blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
 #define MGEA_TS(i) do { if (ts && tid == 0) ts[i] = wall_clock64(); } while (0)
     MGEA_TS(0);
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * COLS;
     const int m0 = blockIdx.y * ROWS;
-    const int kw = a.K / NW, kbeg = wave * kw;
-    const int nchunk = kw >> 5;
+    const int kw = NCH ? 32 * NCH : a.K / NW, kbeg = wave * kw;
+    const int nchunk = NCH ? NCH : kw >> 5;
 
     // LN: the producer's per-tile (mean, M2) partials of this tile's rows, one float4 (two partials) per lane,
     // 16 lanes per row; requested first, merged after the K loop
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     // that the compiler can wait for the statistics alone -- behind a branch it would wait for every load
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        if (LN) load_chunk(d, d < nchunk ? d : nchunk - 1);
+        if (NCH) load_chunk(d, d);
+        else if (LN) load_chunk(d, d < nchunk ? d : nchunk - 1);
         else if (d < nchunk) load_chunk(d, d);
     }
     // QKV epilogue, first hop of its page lookup (branch-free, behind the operand loads): where the row's
@@ -222,12 +228,17 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyArgs a) {
     MGEA_TS(1);
     if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     MGEA_TS(2);
-    for (int ch = 0; ch < nchunk; ch += DEPTH) {
+    if (NCH) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (ch + d < nchunk) {
-                compute_chunk(d);
-                if (ch + d + DEPTH < nchunk) load_chunk(d, ch + d + DEPTH);
+        for (int d = 0; d < DEPTH; ++d) compute_chunk(d);   // every chunk is already in flight
+    } else {
+        for (int ch = 0; ch < nchunk; ch += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (ch + d < nchunk) {
+                    compute_chunk(d);
+                    if (ch + d + DEPTH < nchunk) load_chunk(d, ch + d + DEPTH);
+                }
             }
         }
     }
@@ -380,13 +391,26 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
     a.nw = nw;
     dim3 grid((unsigned)round_up(ceil_div(a.N, 16 * NT), 8), ceil_div(a.M, 16 * MT)), block(64 * nw);
     const size_t shmem = ((size_t)nw * 16 * MT * (16 * NT + 4) + (ln ? 2 * 16 * MT : 0)) * sizeof(float);
+    // compile-time chunk counts for the decode shapes (8 waves x NCH chunks of 32): K = 512 (NCH 2), 768 (3), 2048 (8); anything
+    // else, other wave counts and the timestamp mode of tools/skinny_phases.py take the generic stream (NCH 0)
+    const int nch = (nw == 8 && !(a.dbg & (1 << 20)) && a.K % 256 == 0) ? a.K / 256 : 0;
+#define MGEA_SKINNY_GO(LNV, NTV, F16V, NCHV) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, LNV, MT, NTV, F16V, NCHV>), grid, block, shmem, st, a)
+#define MGEA_SKINNY_NCH(LNV, NTV, F16V)                                                                  \
+    do {                                                                                                 \
+        if (nch == 2) MGEA_SKINNY_GO(LNV, NTV, F16V, 2);                                                  \
+        else if (nch == 3) MGEA_SKINNY_GO(LNV, NTV, F16V, 3);                                             \
+        else if (nch == 8 && MT * NTV <= 2) MGEA_SKINNY_GO(LNV, NTV, F16V, 8);                            \
+        else MGEA_SKINNY_GO(LNV, NTV, F16V, 0);                                                           \
+    } while (0)
     if (a.w_f16) {
-        if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1, true>), grid, block, shmem, st, a);
-        else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT, true>), grid, block, shmem, st, a);
+        if (ln && NT == 1) MGEA_SKINNY_NCH(true, 1, true);
+        else               MGEA_SKINNY_NCH(false, NT, true);
     } else {
-        if (ln && NT == 1) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, MT, 1, false>), grid, block, shmem, st, a);
-        else               hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, MT, NT, false>), grid, block, shmem, st, a);
+        if (ln && NT == 1) MGEA_SKINNY_NCH(true, 1, false);
+        else               MGEA_SKINNY_NCH(false, NT, false);
     }
+#undef MGEA_SKINNY_NCH
+#undef MGEA_SKINNY_GO
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -8,6 +8,11 @@
 //   load       : args + every lane loads 2 x 16 B of the PREVIOUS kernel's output (another CU wrote it) and stores 16 B
 //   load_lds   : load + partial tiles through LDS and a workgroup barrier (the split-K reduction of the skinny GEMM)
 //   load2      : load_lds + a second, dependent load round trip (page table -> page, or statistics -> operands)
+//   big        : like the out-proj skinny GEMM's memory shape: every workgroup loads 32 KB of a static "weight" buffer (shared by
+//                the 4 workgroups of a column tile) + 32 KB of the previous kernel's output (shared by the 32 of a row tile)
+//   big_rmw    : big + the skinny epilogue: 8 per-wave partial tiles through LDS, ONE wave sums them, adds a residual it loaded
+//                from the output buffer (read-modify-write of x) and stores 16 B per lane
+//   big_mfma   : big_rmw + 16 dependent v_mfma_f32_16x16x4_f32 per wave (the exact-fp32 K loop of K = 512 split over 8 waves)
 // build: hipcc -O3 --offload-arch=gfx950 [-mllvm -amdgpu-kernarg-preload-count=16] tools/micro/kernel_floor.hip -o tools/micro/kernel_floor
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -50,6 +55,48 @@ __global__ __launch_bounds__(512) void k_load(Args a) {
     }
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int MODE>   // 0 big, 1 big_rmw, 2 big_mfma
+__global__ __launch_bounds__(512) void k_big(Args a, const float* wbuf) {
+    extern __shared__ float red[];
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+    const int ct = b & 31, rt = b >> 5;                   // 32 column tiles x (gridDim.x / 32) row tiles
+    const float4* w = reinterpret_cast<const float4*>(wbuf) + (size_t)ct * 2048 + wave * 256 + lane;          // 32 KB per column tile
+    const float4* x = reinterpret_cast<const float4*>(a.in) + (size_t)rt * 2048 + wave * 256 + lane;         // 32 KB per row tile
+    float4 wv[4], xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wv[i] = w[i * 64]; xv[i] = x[i * 64]; }
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* outp = reinterpret_cast<float4*>(a.out) + (size_t)rt * 2048 + ct * 64 + lane;   // 64 lanes x 16 B = this tile of the next input
+    if (MODE >= 1 && wave == 0) r4 = *outp;               // residual, requested before the reduction
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].x, xv[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].y, xv[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].z, xv[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].w, xv[i].w, acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[0] += wv[i].x * xv[i].x; acc[1] += wv[i].y * xv[i].y; acc[2] += wv[i].z * xv[i].z; acc[3] += wv[i].w * xv[i].w; }
+    }
+    if (MODE == 0) {
+        if (wave == 0) *outp = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else if (acc[0] == 123.456f) a.out[0] = acc[1];
+        return;
+    }
+    reinterpret_cast<float4*>(red)[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (wave == 0) {
+        float4 s = r4;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) { const float4 p = reinterpret_cast<float4*>(red)[w8 * 64 + lane]; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+        *outp = s;
+    }
+}
+
 int main(int argc, char** argv) {
     const int NB = argc > 1 ? atoi(argv[1]) : 256, CH = 64, REP = 50;
     float *bufA, *bufB; int* idx;
@@ -57,8 +104,9 @@ int main(int argc, char** argv) {
     CK(hipMemset(bufA, 0, (size_t)NB * 1024 * 16 * 2)); CK(hipMemset(bufB, 0, (size_t)NB * 1024 * 16 * 2));
     int* h = (int*)malloc(NB * 4); for (int i = 0; i < NB; ++i) h[i] = (i * 37) % NB; CK(hipMemcpy(idx, h, NB * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
-    const char* names[] = {"empty", "args", "args_pre", "load", "load_lds", "load2"};
-    for (int v = 0; v < 6; ++v) {
+    float* wbuf; CK(hipMalloc(&wbuf, 32 * 2048 * 16)); CK(hipMemset(wbuf, 0, 32 * 2048 * 16));
+    const char* names[] = {"empty", "args", "args_pre", "load", "load_lds", "load2", "big", "big_rmw", "big_mfma"};
+    for (int v = 0; v < 9; ++v) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < CH; ++i) {
@@ -70,6 +118,9 @@ int main(int argc, char** argv) {
                 case 3: hipLaunchKernelGGL(k_load<0>, dim3(NB), dim3(512), 0, st, a); break;
                 case 4: hipLaunchKernelGGL(k_load<1>, dim3(NB), dim3(512), 8192, st, a); break;
                 case 5: hipLaunchKernelGGL(k_load<2>, dim3(NB), dim3(512), 8192, st, a); break;
+                case 6: hipLaunchKernelGGL(k_big<0>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                case 7: hipLaunchKernelGGL(k_big<1>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                case 8: hipLaunchKernelGGL(k_big<2>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
             }
         }
         CK(hipStreamEndCapture(st, &g));
