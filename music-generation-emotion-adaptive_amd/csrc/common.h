@@ -222,6 +222,7 @@ struct SkinnyArgs {
                                             // w_f16 with ln_c1: gamma is applied to A on load (W stays the plain rounded matrix,
                                             // ln_c1 = sum_k gamma_k W[n,k], bias = sum_k beta_k W[n,k] + b[n])
     const float* stats_in; int n_part; int part_cnt;
+    float inv_n_part, inv_k;   // 1 / n_part and 1 / (n_part * part_cnt), filled by the launcher (no division in the kernel)
     // outputs
     float* out; int ldo;       // QKV: qkv_out [M, N]; RES: x [M, N] (in place); ACT: out [M, ldo]; LOGITS: logits or NULL
     float* stats_out;          // RES: [64][N/16][2]
