@@ -160,7 +160,7 @@ def whole_step_bytes(geo, B, Tp, n_steps, e_w, e_kv):
     return sum(p_step * e_w + B * NL * 2 * C_ * e_kv * (Tp + i + 1 + 1) for i in range(n_steps))
 
 
-def prefill_extra(arena, device, B=64, T=1024, reps=3):
+def prefill_extra(arena, device, B=64, T=1024, reps=5):
     """north_star: ">= 50 % MFMA-roofline on prefill".  Decoder-S [64, 1024] non-causal prefill with the logits of every
     position (api_cache.py:87-106 returns them; SURVEY §8d: 3.86 TFLOP = dense 3.03 + attention 0.82)."""
     from mgea import synth
@@ -170,17 +170,21 @@ def prefill_extra(arena, device, B=64, T=1024, reps=3):
     out = {}
     C_, NL, V = DEC["d_model"], DEC["n_layer"], DEC["vocab"]
     for name, want_logits in (("with_logits", True), ("cache_fill_only", False)):
-        eng.reset_and_prefill(ids, want_logits=want_logits)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(2):              # the GPU has just idled through the CPU baseline: let clocks and allocator settle
             lg = eng.reset_and_prefill(ids, want_logits=want_logits)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        times = []
+        for _ in range(reps):           # each repetition timed on its own; the median is robust against a one-off allocator stall
+            del lg
+            t0 = time.perf_counter()
+            lg = eng.reset_and_prefill(ids, want_logits=want_logits)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
         del lg
+        dt = sorted(times)[len(times) // 2]
         flops = 2 * B * T * (NL * 12 * C_ * C_ + (V * C_ if want_logits else 0)) + 4 * B * T * T * C_ * NL
         out[name] = dict(ms=dt * 1e3, tokens_per_sec=B * T / dt, tflops=flops / dt / 1e12, algorithmic_tflop=flops / 1e12,
-                         frac_of_f32_mfma_peak=flops / dt / 1e12 / 157.3)
+                         frac_of_f32_mfma_peak=flops / dt / 1e12 / 157.3, ms_each=[round(t * 1e3, 2) for t in times])
     eng.close()
     w = out["with_logits"]
     return dict(metric="decoder_prefill_tokens_per_sec", value=w["tokens_per_sec"], unit="tokens/s", ms=w["ms"], dtype="f32",
@@ -382,13 +386,14 @@ def main():
         if not args.no_cpu and world == 1:      # the CPU baseline and the extras are N = 1 legs (rank 0 would stall the others)
             line["cpu_baseline"] = cpu_baseline_decoder(sd, prompts.tolist(), args.cpu_seconds)
         extra = {}
-        if not args.no_bert and not args.no_extra and world == 1:
-            extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu)
-            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")
         if world == 1 and not args.no_extra:
             eng.close()
             eng = None
             extra["decoder_prefill"] = prefill_extra(arena, device)
+        if not args.no_bert and not args.no_extra and world == 1:
+            extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu)
+            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")
+        if world == 1 and not args.no_extra:
             # BASELINE configs[4] as written: fp16 storage, top-p 0.9, 2048 tokens, captured step graph (one GPU's share)
             top_p = dict(temperature=1.0, top_k=None, top_p=0.9, seed=1)
             extra["decoder_L"] = decoder_gen_extra(device, DEC_L, 12, 64, 5, 2048, "f16", top_p,

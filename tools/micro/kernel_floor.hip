@@ -13,6 +13,12 @@
 //   big_rmw    : big + the skinny epilogue: 8 per-wave partial tiles through LDS, ONE wave sums them, adds a residual it loaded
 //                from the output buffer (read-modify-write of x) and stores 16 B per lane
 //   big_mfma   : big_rmw + 16 dependent v_mfma_f32_16x16x4_f32 per wave (the exact-fp32 K loop of K = 512 split over 8 waves)
+//   rot_code   : big_mfma, but consecutive kernels of the chain are 6 DIFFERENT copies of the code (like QKV / attention / out-proj / FC1 /
+//                FC2 of a layer): does a kernel that follows different code pay for its instruction fetch?
+//   rot_cfg    : big_mfma, consecutive kernels alternate launch configuration (128 workgroups / 8 KB LDS, 192 / 40 KB, 256 / 20 KB):
+//                does the dispatcher charge for a change of grid size and LDS allocation between dependent kernels?
+//   cold_w     : big_mfma with the 1 MB of "weights" of kernel i taken from one of 96 different 1 MB buffers (like the 92.7 MB of a
+//                decode step: a kernel's weights were last read ~96 kernels ago, so they come from beyond the 32 MB of L2)
 // build: hipcc -O3 --offload-arch=gfx950 [-mllvm -amdgpu-kernarg-preload-count=16] tools/micro/kernel_floor.hip -o tools/micro/kernel_floor
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(512) void k_load(Args a) {
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
-template <int MODE>   // 0 big, 1 big_rmw, 2 big_mfma
+template <int MODE, int ID = 0>   // 0 big, 1 big_rmw, 2 big_mfma; ID: distinct copies of the same code (different code addresses)
 __global__ __launch_bounds__(512) void k_big(Args a, const float* wbuf) {
     extern __shared__ float red[];
     const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
@@ -100,13 +106,14 @@ __global__ __launch_bounds__(512) void k_big(Args a, const float* wbuf) {
 int main(int argc, char** argv) {
     const int NB = argc > 1 ? atoi(argv[1]) : 256, CH = 64, REP = 50;
     float *bufA, *bufB; int* idx;
-    CK(hipMalloc(&bufA, (size_t)NB * 1024 * 16 * 2)); CK(hipMalloc(&bufB, (size_t)NB * 1024 * 16 * 2)); CK(hipMalloc(&idx, NB * 4));
+    const size_t NBM = NB > 256 ? NB : 256;
+    CK(hipMalloc(&bufA, NBM * 1024 * 16 * 2)); CK(hipMalloc(&bufB, NBM * 1024 * 16 * 2)); CK(hipMalloc(&idx, NB * 4));
     CK(hipMemset(bufA, 0, (size_t)NB * 1024 * 16 * 2)); CK(hipMemset(bufB, 0, (size_t)NB * 1024 * 16 * 2));
     int* h = (int*)malloc(NB * 4); for (int i = 0; i < NB; ++i) h[i] = (i * 37) % NB; CK(hipMemcpy(idx, h, NB * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
-    float* wbuf; CK(hipMalloc(&wbuf, 32 * 2048 * 16)); CK(hipMemset(wbuf, 0, 32 * 2048 * 16));
-    const char* names[] = {"empty", "args", "args_pre", "load", "load_lds", "load2", "big", "big_rmw", "big_mfma"};
-    for (int v = 0; v < 9; ++v) {
+    float* wbuf; CK(hipMalloc(&wbuf, (size_t)96 << 20)); CK(hipMemset(wbuf, 0, (size_t)96 << 20));
+    const char* names[] = {"empty", "args", "args_pre", "load", "load_lds", "load2", "big", "big_rmw", "big_mfma", "cold_w", "rot_code", "rot_cfg"};
+    for (int v = 0; v < 12; ++v) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < CH; ++i) {
@@ -121,6 +128,24 @@ int main(int argc, char** argv) {
                 case 6: hipLaunchKernelGGL(k_big<0>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
                 case 7: hipLaunchKernelGGL(k_big<1>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
                 case 8: hipLaunchKernelGGL(k_big<2>, dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                case 9: hipLaunchKernelGGL(k_big<2>, dim3(NB), dim3(512), 8192, st, a, wbuf + (size_t)((i * 37) % 96) * (1 << 18)); break;
+                case 10:
+                    switch (i % 6) {
+                        case 0: hipLaunchKernelGGL((k_big<2, 1>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                        case 1: hipLaunchKernelGGL((k_big<2, 2>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                        case 2: hipLaunchKernelGGL((k_big<2, 3>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                        case 3: hipLaunchKernelGGL((k_big<2, 4>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                        case 4: hipLaunchKernelGGL((k_big<2, 5>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                        default: hipLaunchKernelGGL((k_big<2, 6>), dim3(NB), dim3(512), 8192, st, a, wbuf); break;
+                    }
+                    break;
+                case 11:
+                    switch (i % 3) {
+                        case 0: hipLaunchKernelGGL((k_big<2, 1>), dim3(128), dim3(512), 8192, st, a, wbuf); break;
+                        case 1: hipLaunchKernelGGL((k_big<2, 2>), dim3(192), dim3(512), 40000, st, a, wbuf); break;
+                        default: hipLaunchKernelGGL((k_big<2, 3>), dim3(256), dim3(512), 20000, st, a, wbuf); break;
+                    }
+                    break;
             }
         }
         CK(hipStreamEndCapture(st, &g));
