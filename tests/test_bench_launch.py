@@ -54,3 +54,18 @@ def test_launcher_command_is_the_drivers():
                        "--master-port", "29511", "bench.py", "--gpus", "4"]
     with pytest.raises(ValueError):
         launch.spawn_ranks("bench.py", [], 1)
+
+
+def test_algorithmic_bytes_match_the_survey_figures():
+    """Decoder-S, B = 64, 1019 steps = 921.5 GB in fp32 (14.13 MB per token) / 460.8 GB at 2 bytes; the
+    whole-step HBM fraction of the bench line is computed from exactly this formula."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    f32 = b.whole_step_bytes(b.DEC, 64, 5, 1019, 4, 4)
+    f16 = b.whole_step_bytes(b.DEC, 64, 5, 1019, 2, 2)
+    assert abs(f32 / 1e9 - 921.5) < 0.5 and abs(f16 / 1e9 - 460.8) < 0.3
+    assert abs(f32 / (64 * 1019) / 1e6 - 14.13) < 0.01
+    C, NL, V = b.DEC["d_model"], b.DEC["n_layer"], b.DEC["vocab"]
+    assert NL * (12 * C * C + 13 * C) + V * C + V == 23_184_516          # P_step of SURVEY §8d
