@@ -591,7 +591,6 @@ int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
                      int ldc, int M, int N, int K, int epi, hipStream_t st) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
-    if (const char* ld = getenv("MGEA_BF16_GEMM_LD")) lda = ldw = atoi(ld);   // timing experiments only (wrong results)
     if (M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && !getenv("MGEA_BF16_GEMM_SMALL")) {
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
         bf16_t* c = (bf16_t*)C;
