@@ -8,9 +8,9 @@
 //   XOR-swizzled by row&7 (conflict-free ds_write_b128 staging and ds_read_b128 fragments),
 //   register-staged double buffering (next tile's global loads fly under this tile's MFMAs), XCD-aware
 //   tile order, "swapped" MFMA so a lane owns 4 consecutive output columns (8-byte bf16 stores).
-// * attn_bf16_kernel: flash attention over a packed bf16 qkv buffer with an optional key mask;
-//   S^T = K Q^T keeps the query on lane&15, so the softmax is in-lane + two shuffles and the fp32
-//   accumulators, converted to bf16, ARE the B operand of O^T = V^T P^T (k-permutation shared by V^T).
+// * attn_bf16_kernel: persistent, LDS-DMA double-buffered flash attention over a packed bf16 qkv buffer with an optional key
+//   mask; S^T = K Q^T keeps the query on lane&15, so the softmax is in-lane + two permlane swaps and the fp32 accumulators,
+//   converted to bf16, ARE the B operand of O^T = V^T P^T (k-permutation shared by V^T, which is read with ds_read_b64_tr_b16).
 // * layernorm / embedding kernels: bf16 in/out, fp32 statistics.
 #include <stdlib.h>
 
@@ -332,6 +332,13 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byt
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// Same, with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane (no 64-bit vector address arithmetic).
+__device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
 template <int EPI>
@@ -724,127 +731,299 @@ int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipSt
 }
 
 // ------------------------------------------------------------------------------------------
-// Flash attention, bf16 in/out, head_dim 64.  Workgroup = 64 queries of one (b, h); 4 waves x 16.
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                       bf16_t* __restrict__ out, int T, int H, float scale) {
-    constexpr int DH = 64;
-    constexpr int VT_LD = 68;                       // bf16 elements per V^T row: 136-B pitch, conflict-free b64 reads
-    __shared__ float4 sK[64 * 8];                   // [key][8 x 16 B], chunk ^= key & 7
-    __shared__ __attribute__((aligned(16))) bf16_t sVt[DH * VT_LD];  // [d][key]
-    __shared__ int sValid[64];
+// Reductions over the four lanes c, c + 16, c + 32, c + 48 (the lanes that share a query in the K Q^T accumulator) with gfx950's
+// v_permlane32_swap / v_permlane16_swap: VALU instructions, no trip through the LDS pipeline like ds_bpermute (__shfl_xor), which
+// matters at 2 waves per SIMD where nothing hides that latency.  swap(x, x) leaves [lo, lo] / [hi, hi] (32) or [r0 r0 r2 r2] / [r1 r1
+// r3 r3] (16) in the two results, so one max of the pair is the xor-32 / xor-16 butterfly step.
+__device__ __forceinline__ float quad_max(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// ------------------------------------------------------------------------------------------
+// Flash attention, bf16 in/out, head_dim 64.  PERSISTENT and software-pipelined: 2 workgroups per CU walk the work items
+// (b, h, block of 128 queries); 4 waves x 32 queries (two 16-query MFMA column blocks per wave, every V fragment read from LDS feeds
+// two MFMAs).  Keys are staged 128 at a time -- for the DistilBERT shape (T = 128) K and V of a (b, h) leave HBM exactly once --
+// by LDS-DMA into one of two 32 KB stages: the DMA of unit u + 1 is issued right after the barrier that opens unit u and flies under
+// u's MFMAs, softmax and output stores.  (Without it every workgroup of a round loads, computes and stores in step with all the
+// others: 54 us = 27 load + 16 + 11, the phases add up.)  The DMA is issued from inline asm (glds16_hidden) so that hipcc does not
+// drain vmcnt in front of every LDS read; the only wait for it is the explicit vmcnt(0) at the top of a unit, where nothing younger
+// is in flight.
+//   K image [key][8 x 16 B], chunk ^= key & 7            : row reads (ds_read_b128) for the A operand of K Q^T, conflict-free
+//   V image [key][8 x 16 B], chunk ^= ((key >> 1) & 3) * 2: read with ds_read_b64_tr_b16, the hardware transpose (guide T10): lanes
+//      16g..16g+15 fetch a block of 4 keys x 16 d and lane c gets column d = 16 dt + c of the 4 keys -- the V^T A-operand of the
+//      P V product without a transposing write pass.  The 8 rows a 32-lane half touches land on 8 different 8-bank groups.
+//   Both swizzles are applied on the GLOBAL side of the DMA (a lane picks which 16 bytes of its key's row it fetches); the LDS side
+//   of a DMA is lane-linear.  EXEC is all ones at every transposed read (uniform control flow only).
+// S^T = K Q^T keeps a query's scores lane-local (lane = query, registers = keys 16 kt + 4 g + r); the k index of the P V product is
+// permuted to match (k = 8 g + j  <->  key 32 p + 16 (j >> 2) + 4 g + (j & 3)), so P goes from accumulator to operand in registers.
+// The output tile goes through the (then free) K image so that every store instruction writes complete 128-byte rows.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ mask, bf16_t* __restrict__ out, int T, int H,
+                      int n_items, int nqb, float scale) {
+    constexpr int DH = 64, KB = 128;
+    constexpr int STAGE = 2048;                                   // 16-byte chunks: K image, then V image
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE], then [2][2] 64-bit validity words
+    unsigned long long* sValid = reinterpret_cast<unsigned long long*>(lds + 2 * STAGE);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
 
     const int C = H * DH;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)b * T;
+    const int nkb = (T + KB - 1) / KB;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-    int qrow = q0 + wave * 16 + c;
-    const bool q_in = qrow < T;
-    qrow = q_in ? qrow : T - 1;
-    bf16x8 qf[2];  // d = 32*ks + 8g .. +7, pre-scaled by 1/sqrt(dh) (a power of two: exact in bf16)
+    // DMA of one unit (item, key block) into a stage: wave w moves keys 32 w .. 32 w + 31 of K and of V (8 instructions of 1 KB)
+    const int d_key = lane >> 3, d_ch = lane & 7;                 // this lane's slot inside an 8-key piece
+    const unsigned dk_off = 2u * C + 16u * (d_ch ^ d_key);                              // K: chunk ^ (key & 7), key & 7 == d_key
+    const unsigned dv_off = 4u * C + 16u * (d_ch ^ (((d_key >> 1) & 3) << 1));          // V: chunk ^ 2 ((key >> 1) & 3)
+    auto issue = [&](int it, int kbi, int st) {
+        const int bh = it / nqb, bb = bh / H, hh = bh - bb * H;   // wave-uniform: the base stays in SGPRs
+        const bf16_t* base = qkv + (int64_t)bb * T * 3 * C + hh * DH;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * 3 * C + h * DH + ks * 32 + 8 * g);
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i, key = piece * 8 + d_key;
+            int kr = kbi * KB + key; kr = kr < T ? kr : T - 1;
+            const unsigned row = (unsigned)kr * (unsigned)(6 * C);    // bytes; a sequence's rows span < 4 GB (checked on the host)
+            const unsigned dst = lds_base + (unsigned)(st * STAGE + piece * 64) * 16u;
+            glds16_hidden_s(base, row + dk_off, dst);
+            glds16_hidden_s(base, row + dv_off, dst + 1024u * 16u);
+        }
+    };
+    auto mask_of = [&](int it, int kbi) -> int {                  // validity of key kbi * 128 + tid (waves 0 and 1)
+        const int bh = it / nqb, bb = bh / H;
+        const int kidx = kbi * KB + tid;
+        int ok = (tid < KB && kidx < T) ? 1 : 0;
+        if (ok && mask) ok = mask[(int64_t)bb * T + kidx];
+        return ok;
+    };
+    bf16x8 qn[2][2];                                              // next item's raw Q fragments
+    auto load_q = [&](int it) {
+        const int bh = it / nqb, qb = it - bh * nqb, bb = bh / H, hh = bh - bb * H;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16_t)((float)t[j] * scale);
+        for (int mq = 0; mq < 2; ++mq) {
+            int qr = qb * 128 + wave * 32 + mq * 16 + c; qr = qr < T ? qr : T - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                qn[mq][ks] = *reinterpret_cast<const bf16x8*>(qkv + ((int64_t)bb * T + qr) * 3 * C + hh * DH + ks * 32 + 8 * g);
+        }
+    };
+    // transposed-read offsets (bf16 elements) of this lane inside a 16-key group of the V image, one per 16-d block:
+    // row 4 g + (c >> 2) of the group, 16-byte chunk (2 dt + ((c & 3) >> 1)) ^ swizzle(row), half (c & 1)
+    int v_off[4];
+    {
+        const int vrow = 4 * g + (c >> 2), sw = ((vrow >> 1) & 3) << 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) v_off[dt] = vrow * 64 + (((2 * dt + ((c & 3) >> 1)) ^ sw) * 8) + 4 * (c & 1);
     }
-    f32x4 oacc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mx = -INFINITY, lsum = 0.f;
 
-    const int ntiles = (T + 63) >> 6;
-    for (int kt0 = 0; kt0 < ntiles; ++kt0) {
-        const int k0 = kt0 * 64;
+    // The output rows of an item are held in registers and stored one unit later, behind the next DMA issue: a store issued at the
+    // end of a unit would be waited for (vmcnt(0), loads and stores share the counter) at the top of the next one with nothing to hide
+    // its latency behind -- 2-3 us per item.
+    float4 ov0, ov1, ov2, ov3;                                    // (scalars, not an array: an array captured by a lambda went to scratch)
+    bf16_t* optr = nullptr;                                       // row of ov0; ov<i> is 8 i rows further; nullptr: nothing held
+    int orow = 0;                                                 // query index of ov0 within the sequence
+#define MGEA_FLUSH_OUT()                                                                               \
+    if (optr) {                                                                                        \
+        if (orow < T)      *reinterpret_cast<float4*>(optr) = ov0;                                     \
+        if (orow + 8 < T)  *reinterpret_cast<float4*>(optr + (int64_t)8 * C) = ov1;                    \
+        if (orow + 16 < T) *reinterpret_cast<float4*>(optr + (int64_t)16 * C) = ov2;                   \
+        if (orow + 24 < T) *reinterpret_cast<float4*>(optr + (int64_t)24 * C) = ov3;                   \
+    }
+    int item = blockIdx.x, kb = 0, stage = 0, mk = 0;
+    if (item < n_items) { issue(item, 0, 0); mk = mask_of(item, 0); load_q(item); }
+    bf16x8 qf[2][2];
+    f32x4 oacc[2][4], lacc[2];                                    // lacc: row sums of P, from an all-ones A operand (every row equal)
+    float mx[2];                                                  // running maximum of the RAW scores q . k
+    const float kexp = scale * 1.4426950408889634f;               // exp(scale * (s - m)) = 2^((s - m) * kexp)
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    while (item < n_items) {
+        // unit (item, kb) has landed: nothing younger than its DMA, its mask word and (kb == 0) its Q rows is in flight here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Tell hipcc that the prefetched registers are complete on every path.  It does not read the wait above, and a load it still
+        // believes pending makes it wait (by ITS count, which does not include the hidden DMAs: in effect vmcnt(0)) before those
+        // registers are written again -- right after the next unit's DMA was issued, which would serialise the pipeline.
+        asm volatile("" : "+v"(qn[0][0]), "+v"(qn[0][1]), "+v"(qn[1][0]), "+v"(qn[1][1]), "+v"(mk));
+        if (tid < KB) {
+            const unsigned long long bal = __ballot(mk != 0);
+            if (lane == 0) sValid[stage * 2 + wave] = bal;
+        }
         __syncthreads();
+        if (kb == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {   // 64 keys x 8 chunks = 512 chunks of K and of V
-            const int idx = tid + i * 256, key = idx >> 3, ch = idx & 7;
-            int kr = k0 + key; kr = kr < T ? kr : T - 1;
-            const bf16_t* src = qkv + (row0 + kr) * 3 * C + h * DH + ch * 8;
-            sK[key * 8 + (ch ^ (key & 7))] = *reinterpret_cast<const float4*>(src + C);
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 2 * C);
+            for (int mq = 0; mq < 2; ++mq) {
+                mx[mq] = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VT_LD + key] = v[j];   // transpose on write
+                for (int dt = 0; dt < 4; ++dt) oacc[mq][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                lacc[mq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                qf[mq][0] = qn[mq][0];                               // unscaled: 1/sqrt(dh) is folded into the exponent's constant
+                qf[mq][1] = qn[mq][1];
+            }
         }
-        if (tid < 64) {
-            const int kidx = k0 + tid;
-            bool ok = kidx < T;
-            if (ok && mask) ok = mask[row0 + kidx] != 0;
-            sValid[tid] = ok ? 1 : 0;
+        int nitem = item, nkbi = kb + 1;
+        if (nkbi == nkb) { nitem = item + gridDim.x; nkbi = 0; }
+        if (nitem < n_items) {                                    // the other stage was last read before the barrier above
+            issue(nitem, nkbi, stage ^ 1);
+            mk = mask_of(nitem, nkbi);
+            if (nkbi == 0) load_q(nitem);
         }
-        __syncthreads();
+        MGEA_FLUSH_OUT();
+        optr = nullptr;
 
-        f32x4 sc[4];
+        const float4* sK = lds + stage * STAGE;
+        const bf16_t* sV = reinterpret_cast<const bf16_t*>(lds + stage * STAGE + 1024);
+#pragma unroll 1
+        for (int t0 = 0; t0 < KB && kb * KB + t0 < T; t0 += 64) {   // workgroup-uniform bounds
+            const unsigned long long vm = sValid[stage * 2 + (t0 >> 6)];
+            const unsigned vm_lo = __builtin_amdgcn_readfirstlane((unsigned)vm), vm_hi = __builtin_amdgcn_readfirstlane((unsigned)(vm >> 32));
+            const bool all_valid = (vm_lo & vm_hi) == 0xffffffffu;                         // wave-uniform
+            const unsigned vb_lo = vm_lo >> (4 * g), vb_hi = vm_hi >> (4 * g);              // bit 16 (kt & 1) + r of word kt >> 1
+            bf16x8 pf[2][2];  // [query block][32-key half]
+            const bool first_tile = kb == 0 && t0 == 0;
+            // both query blocks side by side: two independent dependency chains per wave (there are only 2 waves per SIMD)
+            f32x4 sc[2][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int key = kt * 16 + c;
+            for (int kt = 0; kt < 4; ++kt) { sc[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const float4 kv = sK[key * 8 + ((ks * 4 + g) ^ (key & 7))];
-                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kv), qf[ks], sc[kt], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int key = t0 + kt * 16 + c;
+                    const float4 kv = sK[key * 8 + ((ks * 4 + g) ^ (key & 7))];
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&kv);
+                    sc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], sc[0][kt], 0, 0, 0);
+                    sc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], sc[1][kt], 0, 0, 0);
+                }
+            float tmax[2];
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq) {
+                tmax[mq] = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    if (!all_valid) {
+                        const unsigned w = (kt >> 1) ? vb_hi : vb_lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[mq][kt][r] = ((w >> (16 * (kt & 1) + r)) & 1u) ? sc[mq][kt][r] : -INFINITY;
+                    }
+                    tmax[mq] = fmaxf(tmax[mq], fmaxf(fmaxf(sc[mq][kt][0], sc[mq][kt][1]), fmaxf(sc[mq][kt][2], sc[mq][kt][3])));
+                }
             }
+            tmax[0] = quad_max(tmax[0]);
+            tmax[1] = quad_max(tmax[1]);
+            // Deferred rescale (guide T13): the running maximum is only a scaling reference; P and the accumulators stay exact as long
+            // as one reference is used per row.  Keep the old one while no row of this wave outgrows it by more than 2^RESCALE_LOG2
+            // (p <= 2^16: nothing near an fp32 / bf16 range limit) -- the accumulator rescale and its exponential then run on the first
+            // tile of an item and on the rare tile that trips the threshold instead of on every tile.
+            constexpr float RESCALE_LOG2 = 16.0f;
+            bool grow = first_tile;
+            if (!first_tile) {
+                const bool g0 = (tmax[0] - mx[0]) * kexp > RESCALE_LOG2, g1 = (tmax[1] - mx[1]) * kexp > RESCALE_LOG2;   // -inf - -inf = NaN: false
+                grow = __any((g0 || g1) ? 1 : 0) != 0;                                                                  // wave-uniform
+            }
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq) {
+                if (grow) {
+                    const float mnew = fmaxf(mx[mq], tmax[mq]);
+                    if (!first_tile) {
+                        // alpha = 2^((m_old - m_new) kexp); rows that had no valid key so far carry zeros: any finite alpha will do
+                        const float alpha = (mx[mq] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mx[mq] - mnew) * kexp);
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            oacc[mq][dt][0] *= alpha; oacc[mq][dt][1] *= alpha; oacc[mq][dt][2] *= alpha; oacc[mq][dt][3] *= alpha;
+                        }
+                        lacc[mq][0] *= alpha; lacc[mq][1] *= alpha; lacc[mq][2] *= alpha; lacc[mq][3] *= alpha;
+                    }
+                    mx[mq] = mnew;
+                }
+                const float nml = (mx[mq] == -INFINITY) ? 0.f : -mx[mq] * kexp;   // a row without a valid key yet: p = 2^(-inf) = 0
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pf[mq][kt >> 1][(kt & 1) * 4 + r] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(sc[mq][kt][r], kexp, nml));
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                         // row sums of the bf16 P the P V product actually uses
+                lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][p], lacc[0], 0, 0, 0);
+                lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][p], lacc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16_t* vb = sV + (t0 + 32 * p) * 64 + v_off[dt];
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 16 * 64));
+                    union { s16x4 s[2]; bf16x8 v; } u;
+                    u.s[0] = lo; u.s[1] = hi;
+                    oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[0][p], oacc[0][dt], 0, 0, 0);
+                    oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[1][p], oacc[1][dt], 0, 0, 0);
+                }
         }
-        float tmax = -INFINITY;
+
+        if (kb == nkb - 1) {
+            const int bh = item / nqb, qb = item - bh * nqb, bb = bh / H, hh = bh - bb * H;
+            __syncthreads();                                      // every wave is done with this stage's K image
+            bf16_t* so = reinterpret_cast<bf16_t*>(lds + stage * STAGE) + wave * (32 * 64);   // [32 queries][64 d], chunk ^= query & 7
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int4 vl = *reinterpret_cast<const int4*>(&sValid[kt * 16 + 4 * g]);
-            sc[kt][0] = vl.x ? sc[kt][0] : -INFINITY;
-            sc[kt][1] = vl.y ? sc[kt][1] : -INFINITY;
-            sc[kt][2] = vl.z ? sc[kt][2] : -INFINITY;
-            sc[kt][3] = vl.w ? sc[kt][3] : -INFINITY;
-            tmax = fmaxf(tmax, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+            for (int mq = 0; mq < 2; ++mq) {
+                const float inv = __builtin_amdgcn_rcpf(lacc[mq][0]);   // 1 ulp, far below the bf16 output rounding
+                const int ql = mq * 16 + c;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x4 o = {(bf16_t)(oacc[mq][dt][0] * inv), (bf16_t)(oacc[mq][dt][1] * inv), (bf16_t)(oacc[mq][dt][2] * inv),
+                                (bf16_t)(oacc[mq][dt][3] * inv)};
+                    const int ch = (dt * 2 + (g >> 1)) ^ (ql & 7);
+                    *reinterpret_cast<bf16x4*>(so + ql * 64 + ch * 8 + 4 * (g & 1)) = o;
+                }
+            }
+            // a wave reads back only what it wrote itself: lane -> row (lane >> 3) + 8 i, 16-byte chunk lane & 7
+            {
+                const int ql = lane >> 3, ch = lane & 7;             // (8 i + ql) & 7 == ql
+                const bf16_t* sp = so + ql * 64 + ((ch ^ ql) * 8);
+                ov0 = *reinterpret_cast<const float4*>(sp);
+                ov1 = *reinterpret_cast<const float4*>(sp + 8 * 64);
+                ov2 = *reinterpret_cast<const float4*>(sp + 16 * 64);
+                ov3 = *reinterpret_cast<const float4*>(sp + 24 * 64);
+            }
+            orow = qb * 128 + wave * 32 + (lane >> 3);
+            optr = out + ((int64_t)bb * T + orow) * C + hh * DH + (lane & 7) * 8;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mx, tmax);
-        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = (mx == -INFINITY) ? 0.f : __expf(mx - msafe);
-        float psum = 0.f;
-        bf16x8 pf[2];  // B operand of PV: k index 8g+j <-> key 32p + 4g + j (j<4), 32p + 16 + 4g + (j-4)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[kt][r] - msafe);
-                psum += p;
-                pf[kt >> 1][(kt & 1) * 4 + r] = (bf16_t)p;
-            }
-        lsum = lsum * alpha + psum;
-        mx = mnew;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha; }
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* vr = sVt + (dt * 16 + c) * VT_LD + 32 * p + 4 * g;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
-                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[p], oacc[dt], 0, 0, 0);
-            }
+        item = nitem; kb = nkbi; stage ^= 1;
     }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (q_in) {
-        const float inv = 1.0f / lsum;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 o = {(bf16_t)(oacc[dt][0] * inv), (bf16_t)(oacc[dt][1] * inv), (bf16_t)(oacc[dt][2] * inv), (bf16_t)(oacc[dt][3] * inv)};
-            *reinterpret_cast<bf16x4*>(out + (row0 + qrow) * C + h * DH + dt * 16 + 4 * g) = o;
-        }
-    }
+    MGEA_FLUSH_OUT();
+#undef MGEA_FLUSH_OUT
 }
 
 int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st) {
     MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
-    dim3 grid(ceil_div(T, 64), H, B);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
-                       1.0f / sqrtf((float)dh));
+    const int nqb = ceil_div(T, 128);
+    const int64_t n_items = (int64_t)B * H * nqb;
+    MGEA_REQUIRE(n_items < (1 << 30), MGEA_EINVAL, "bf16 attention: too many (batch, head, query block) items");
+    MGEA_REQUIRE((int64_t)T * 6 * H * dh < ((int64_t)1 << 32), MGEA_EINVAL, "bf16 attention: one sequence of qkv rows must span < 4 GB");
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        MGEA_CHECK_HIP(hipGetDevice(&dev));
+        MGEA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    const int shmem = 2 * 2048 * 16 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MGEA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+        attr_set = true;
+    }
+    const int grid = (int)(n_items < 2 * n_cu ? n_items : 2 * n_cu);
+    hipLaunchKernelGGL(attn_bf16_kernel, dim3(grid), dim3(256), shmem, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
+                       (int)n_items, nqb, 1.0f / sqrtf((float)dh));
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

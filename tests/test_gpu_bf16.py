@@ -85,6 +85,41 @@ def test_attention_bf16(B, T, H, masked):
     assert float((got.double() - want).abs().max()) < 2.5e-2     # P is rounded to bf16 before the PV product
 
 
+def _attention_ref(qkv, H, valid):
+    B, T, C3 = qkv.shape
+    C, dh = C3 // 3, 64
+    q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, T, H, dh).transpose(1, 2).double() for i in range(3))
+    s = (q @ k.transpose(-1, -2) / 8.0).masked_fill(~valid[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, C)
+
+
+def test_attention_bf16_persistent_walk_and_rescale_paths():
+    """The kernel is persistent (2 workgroups per CU walk the (batch, head, query block) items through two LDS stages) and rescales
+    its accumulators only when a row's maximum outgrows the reference by 2^16: cover (a) more items than workgroups, (b) several
+    key blocks and query blocks per sequence, (c) a later key tile whose scores dwarf the earlier ones (the rescale path),
+    (d) a first key tile that is masked out completely (rows with no valid key until the second tile)."""
+    from mgea import ops
+    # (a) 1152 items on at most 512 workgroups
+    B, T, H = 96, 64, 12
+    qkv = rnd(B, T, 3 * H * 64, seed=11, scale=1.5).bfloat16()
+    valid = torch.ones(B, T, dtype=torch.bool)
+    got = ops.attention_bf16(qkv.cuda(), H, None).cpu()
+    assert float((got.double() - _attention_ref(qkv, H, valid)).abs().max()) < 2.5e-2
+    # (b) + (c) + (d): 3 key blocks x 3 query blocks; keys 64.. scaled up 6x; the first 64 keys masked for batch row 1
+    B, T, H = 3, 300, 2
+    C = H * 64
+    qkv = rnd(B, T, 3 * C, seed=12, scale=1.0)
+    qkv[:, 64:, C:2 * C] *= 6.0
+    qkv = qkv.bfloat16()
+    valid = torch.rand(B, T, generator=torch.Generator().manual_seed(5)) > 0.2
+    valid[:, 70] = True
+    valid[1, :64] = False
+    want = _attention_ref(qkv, H, valid)
+    got = ops.attention_bf16(qkv.cuda(), H, valid.to(torch.int32).cuda()).cpu()
+    # scores reach +-150 here: P is one-hot-ish, the error is the bf16 rounding of P and of the output
+    assert float((got.double() - want).abs().max()) < 4e-2
+
+
 @pytest.mark.parametrize("tag", ["tiny", "base"])
 def test_bert_bf16_engine_vs_golden_fp32(golden, tag):
     from mgea.bert import BertEngine
