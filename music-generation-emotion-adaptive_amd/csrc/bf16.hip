@@ -623,47 +623,84 @@ int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm over bf16 rows (fp32 statistics), in place allowed.  One wave per row, 4 rows/block.
+// LayerNorm over bf16 rows (fp32 statistics), in place allowed.  A wave owns 4 rows and requests all of them (and the affine
+// vectors) before the first reduction: 8-16 loads of 16 bytes in flight per lane instead of 2, four independent reduction chains.
+// (One row per wave ran at 4.2 TB/s of read + write on [32768, 768]: every wave sat through a load, two dependent wave reductions
+// and a second round trip for w / b before its only stores.)
+template <int NCHL>   // 16-byte chunks per lane and row: C <= 512 * NCHL
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, bf16_t* __restrict__ y, int M,
                                                             int C, float eps) {
+    constexpr int RW = 4;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= M) return;
     const int nch = C >> 3;  // 16-byte chunks per row
-    float v[4][8];
-    float s = 0.f;
+    bf16x8 t[RW][NCHL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = lane + i * 64;
-        if (ch < nch) {
-            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + row * C + ch * 8);
+    for (int r = 0; r < RW; ++r) {
+        const int64_t row = row0 + r < M ? row0 + r : M - 1;     // clamped: loaded, never stored
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+        for (int i = 0; i < NCHL; ++i) {
+            const int ch = lane + i * 64;
+            t[r][i] = *reinterpret_cast<const bf16x8*>(x + row * C + (ch < nch ? ch : 0) * 8);
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    float4 wv[NCHL][2], bv[NCHL][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (lane + i * 64 < nch)
+    for (int i = 0; i < NCHL; ++i) {
+        const int ch = lane + i * 64 < nch ? lane + i * 64 : 0;
+        wv[i][0] = ld4(w + ch * 8); wv[i][1] = ld4(w + ch * 8 + 4);
+        bv[i][0] = ld4(b + ch * 8); bv[i][1] = ld4(b + ch * 8 + 4);
+    }
+    const float inv_c = 1.0f / (float)C;
+    float mean[RW], rstd[RW];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    for (int r = 0; r < RW; ++r) {
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = lane + i * 64;
-        if (ch < nch) {
-            bf16x8 o;
+        for (int i = 0; i < NCHL; ++i)
+            if (lane + i * 64 < nch)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mean) * rstd * w[ch * 8 + j] + b[ch * 8 + j]);
-            *reinterpret_cast<bf16x8*>(y + row * C + ch * 8) = o;
+                for (int j = 0; j < 8; ++j) s += (float)t[r][i][j];
+        mean[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) mean[r] = wave_sum(mean[r]) * inv_c;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCHL; ++i)
+            if (lane + i * 64 < nch)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = (float)t[r][i][j] - mean[r]; q += d * d; }
+        rstd[r] = q;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(rstd[r]) * inv_c + eps);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= M) break;
+#pragma unroll
+        for (int i = 0; i < NCHL; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nch) {
+                const float ww[8] = {wv[i][0].x, wv[i][0].y, wv[i][0].z, wv[i][0].w, wv[i][1].x, wv[i][1].y, wv[i][1].z, wv[i][1].w};
+                const float bb[8] = {bv[i][0].x, bv[i][0].y, bv[i][0].z, bv[i][0].w, bv[i][1].x, bv[i][1].y, bv[i][1].z, bv[i][1].w};
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(((float)t[r][i][j] - mean[r]) * rstd[r] * ww[j] + bb[j]);
+                *reinterpret_cast<bf16x8*>(y + (row0 + r) * C + ch * 8) = o;
+            }
         }
     }
 }
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st) {
     MGEA_REQUIRE(C % 8 == 0 && C <= 2048, MGEA_EINVAL, "bf16 layernorm: C=%d must be a multiple of 8 and <= 2048", C);
-    hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, M, C, eps);
+    const dim3 grid(ceil_div(M, 16));
+    if (C <= 1024) hipLaunchKernelGGL(layernorm_bf16_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, M, C, eps);
+    else           hipLaunchKernelGGL(layernorm_bf16_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, M, C, eps);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
