@@ -208,6 +208,16 @@ int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const i
 int mgea_op_f32_to_bf16(const float* src_dev, void* dst_dev, int64_t n, void* stream);
 int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
                       void* out_dev, int32_t M, int32_t N, int32_t K, int32_t epi, void* stream);
+/* The same GEMM with the engine's scratch for the "split tail" schedule of the persistent 256 x 256 kernel: when the output has
+ * more tiles than the GPU has CUs, the tiles left after the full rounds number at most half the workgroups and K >= 2048
+ * (DistilBERT's FFN down-projection: 384 tiles on 256 CUs, K = 3072), each left-over tile is shared by two workgroups, one per
+ * half of K, which meet through scratch_dev (mgea_op_gemm_bf16_scratch_bytes() bytes, first 4 KB zeroed once; launches sharing
+ * one scratch must be stream-ordered).  *epoch_io is a launch counter owned by the caller (start at 0); results are
+ * deterministic.  Other shapes run exactly as mgea_op_gemm_bf16. */
+int64_t mgea_op_gemm_bf16_scratch_bytes(void);
+int mgea_op_gemm_bf16_split(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
+                            void* out_dev, int32_t M, int32_t N, int32_t K, int32_t epi, void* scratch_dev,
+                            int64_t scratch_bytes, int32_t* epoch_io, void* stream);
 int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,
                            int32_t n_head, int32_t head_dim, void* stream);
 int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int32_t M,

@@ -64,6 +64,7 @@ struct mgea_bert {
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *slabs = nullptr, *pooled = nullptr,
           *pooled2 = nullptr;
     void *wb = nullptr, *hb = nullptr, *qkvb = nullptr, *ctxb = nullptr, *ffnb = nullptr, *tmpb = nullptr;  // bf16 mode
+    GemmSplitWs split{nullptr, 0, 0};                        // bf16 mode: scratch of the persistent GEMM's split-tail schedule
     const char* wbf(int64_t off_floats) const { return (const char*)wb + off_floats * 2; }
     int64_t slab_cap = 0;
     const float* w(int i) const { return arena + off[i]; }
@@ -89,7 +90,7 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_destroy(mgea_bert* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb};
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->split.buf};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;
@@ -126,7 +127,10 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
              hipMalloc(&h->qkvb, M * 3 * D * 2) == hipSuccess && hipMalloc(&h->ctxb, M * D * 2) == hipSuccess &&
              hipMalloc(&h->ffnb, M * Hd * 2) == hipSuccess && hipMalloc(&h->tmpb, M * D * 2) == hipSuccess &&
              hipMalloc((void**)&h->slabs, h->slab_cap * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
-             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess &&
+             hipMalloc(&h->split.buf, MGEA_GEMM_SPLIT_WS_BYTES) == hipSuccess &&
+             hipMemset(h->split.buf, 0, 4096) == hipSuccess;                       // the flags; epochs start at 1
+        if (ok) h->split.bytes = MGEA_GEMM_SPLIT_WS_BYTES;
         if (ok) ok = launch_f32_to_bf16(arena_dev, h->wb, total, nullptr) == MGEA_OK && hipDeviceSynchronize() == hipSuccess;
     } else {
         ok = hipMalloc((void**)&h->h, M * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, M * 3 * D * 4) == hipSuccess &&
@@ -168,12 +172,12 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
                                            S, D, c.vocab, st));
         for (int l = 0; l < c.n_layers; ++l) {
-            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st));
+            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st, &h->split));
             MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
-            MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2, st));
+            MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2, st, &h->split));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->hb, M, D, c.ln_eps, st));
-            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_L1W), D, h->lw(l, BL_L1B), nullptr, h->ffnb, Hd, M, Hd, D, 1, st));
-            MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2, st));
+            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_L1W), D, h->lw(l, BL_L1B), nullptr, h->ffnb, Hd, M, Hd, D, 1, st, &h->split));
+            MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2, st, &h->split));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
         }
         MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));

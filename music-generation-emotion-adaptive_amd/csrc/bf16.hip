@@ -344,7 +344,8 @@ __device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned voff
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles) {
+                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
+                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch) {
     constexpr int BM = 256, BN = 256;
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;     // in 16-byte chunks: A tile, then the W tile
     constexpr int CST = 2 * STAGE;                         // the epilogue's own 32 KB behind the two operand stages
@@ -360,16 +361,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
     // only): XCD r = b % 8 gets the contiguous run of tiles [r * n_tiles / 8, (r + 1) * n_tiles / 8) so that the tiles in flight on
     // one L2 share A and W panels; the run is walked by the XCD's workgroups with stride gridDim.x / 8.
     const int wg_x = gridDim.x >> 3;                         // host: gridDim.x % 8 == 0
-    int slot = (int)blockIdx.x >> 3;
+    const int slot = (int)blockIdx.x >> 3;
     const int run0 = ((int)blockIdx.x & 7) * ((n_tiles + 7) >> 3);
     const int per_x = (run0 + ((n_tiles + 7) >> 3) < n_tiles ? ((n_tiles + 7) >> 3) : n_tiles - run0);   // tiles in this XCD's run (<= 0: none)
+    // SPLIT TAIL: 384 tiles on 256 workgroups are one full round and a half-empty one.  When the tiles left over after the full
+    // rounds number at most half the XCD's workgroups, each of them is shared by two workgroups, one per half of K, which swap
+    // half of their fp32 partial sums through the engine's scratch and finalise half of the tile each (see the exchange below).
+    // Neither waits before it has published its own half, so the pair cannot deadlock; both are co-resident (one workgroup per
+    // CU).  The exchange costs ~15-20 us (256 KB per workgroup through the coherence point + the skew of the pair), half a tile
+    // saves 0.75 us per K-tile: worth it from K = 2048 on (measured, tools/gemm_bf16_bench.py: K = 3072 167 -> 148 us, K = 768
+    // 60 -> 63 and 124 -> 135 us), so K = 768 keeps its whole tiles.
+    const int full_rounds = per_x > 0 ? per_x / wg_x : 0, rem = per_x > 0 ? per_x - full_rounds * wg_x : 0;
+    const bool split = split_ws && rem > 0 && 2 * rem <= wg_x && KT >= 32;
+    int u_tile = 0, u_kt0 = 0, u_nkt = 0, u_mode = 0;       // mode 0: whole tile, 1 / 2: first / second half of K of a shared tile
+    auto get_unit = [&](int ui) -> bool {                   // the ui-th unit of this workgroup
+        if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_kt0 = 0; u_nkt = KT; u_mode = 0; return true; }
+        if (ui > full_rounds) return false;
+        if (split) {
+            if (slot >= 2 * rem) return false;
+            u_tile = run0 + full_rounds * wg_x + (slot >> 1);
+            u_kt0 = (slot & 1) ? KT / 2 : 0; u_nkt = (slot & 1) ? KT - KT / 2 : KT / 2; u_mode = 1 + (slot & 1);
+            return true;
+        }
+        if (slot >= rem) return false;
+        u_tile = run0 + full_rounds * wg_x + slot; u_kt0 = 0; u_nkt = KT; u_mode = 0;
+        return true;
+    };
+    const int split_idx = ((int)blockIdx.x & 7) * (wg_x >> 1) + (slot >> 1);   // this workgroup's pair in the scratch
 
     // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
     // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
     const bf16_t* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
     int m0 = 0, n0 = 0;
-    auto set_tile = [&](int t) {
+    auto set_tile = [&](int t, int kt0) {
         m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -377,10 +402,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             for (int i = 0; i < 2; ++i) {
                 int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
                 ra = ra < M ? ra : M - 1;
-                src[hf][i] = A + (int64_t)ra * lda + lch * 8;
+                src[hf][i] = A + (int64_t)ra * lda + lch * 8 + kt0 * 64;
                 int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
                 rw = rw < N ? rw : N - 1;
-                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
+                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8 + kt0 * 64;
             }
     };
     auto issue_half = [&](int hid, int kt) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
@@ -394,14 +419,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
     };
     // tile 0 whole, then the first two half-tiles of tile 1 (the steady state issues W0 / A0 of K-tile u+2 in phases 4u+2 / 4u+3
     // and W1 / A1 of K-tile u+1 in phases 4u / 4u+1)
-    auto issue_prologue = [&]() {
+    auto issue_prologue = [&](int nkt) {
         issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
-        if (KT > 1) { issue_half(2, 1); issue_half(0, 1); }
+        if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); }
     };
 
-    if (slot < per_x) { set_tile(run0 + slot); issue_prologue(); }
-    while (slot < per_x) {
+    int ui = 0;
+    bool have = get_unit(0);
+    if (have) { set_tile(u_tile, u_kt0); issue_prologue(u_nkt); }
+    while (have) {
         const int cm0 = m0, cn0 = n0;                       // this tile's origin (set_tile moves on to the next one below)
+        const int nkt = u_nkt, mode = u_mode;               // this unit's K-tiles: [u_kt0, u_kt0 + nkt), folded into src[] by set_tile
         f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
 #pragma unroll
         for (int n = 0; n < 4; ++n)
@@ -409,13 +437,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // K-tile 0 has landed when at most the 4 DMAs of K-tile 1's first halves are still in flight.  (After the first tile the
         // previous epilogue's stores are younger than these DMAs and count too: the wait is then stronger, never weaker.)
-        if (KT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
 
         bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
-        for (int u = 0; u < KT; ++u) {
+        for (int u = 0; u < nkt; ++u) {
             const float4* sb = lds + (u & 1) * STAGE;
             const float4* sa = sb + (wm * 128) * 8;
             const float4* sw = sb + SA + (wn * 64) * 8;
@@ -442,13 +470,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (p == 0 && u + 1 < KT) issue_half(3, u + 1);
-                if (p == 1 && u + 1 < KT) issue_half(1, u + 1);
-                if (p == 2 && u + 2 < KT) issue_half(2, u + 2);
-                if (p == 3 && u + 2 < KT) issue_half(0, u + 2);
+                if (p == 0 && u + 1 < nkt) issue_half(3, u + 1);
+                if (p == 1 && u + 1 < nkt) issue_half(1, u + 1);
+                if (p == 2 && u + 2 < nkt) issue_half(2, u + 2);
+                if (p == 3 && u + 2 < nkt) issue_half(0, u + 2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
                 if (p == 3 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(4u+3) ...
-                    if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                         }
                 __builtin_amdgcn_s_setprio(0);
                 if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
-                    if (u + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -484,8 +512,64 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             const int col = cn0 + wn * 64 + n * 16 + 4 * g;
             bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        slot += wg_x;
-        if (slot < per_x) { set_tile(run0 + slot); issue_prologue(); }
+        have = get_unit(++ui);
+        if (have) { set_tile(u_tile, u_kt0); issue_prologue(u_nkt); }
+
+        int mshift = 0, kpass = 4;                             // epilogue: m-tile of acc[.][j] is j + mshift; passes of 2 m-tiles
+        if (mode != 0) {
+            // Split units come last (have == false): no DMA is in flight.  SYMMETRIC exchange: both workgroups of the pair hold partial
+            // sums of the whole tile (their half of K); workgroup h finalises the m-tiles 4h .. 4h+3 of every wave and ships the
+            // other four to its partner.  After the swap below the code is the same for both (one path: a producer path and a consumer
+            // path side by side, each with 128 live accumulators, pushed spills into the MFMA loop of a kernel without a register to
+            // spare): acc[.][0..3] = mine, acc[.][4..7] = the partner's.
+            // Coherence without fences: an agent-scope release / acquire pair writes back and invalidates a whole L2 on this 8-XCD part
+            // (+100 us per GEMM when it was tried); the partials are written and read with relaxed AGENT-scope atomics instead (sc1:
+            // through to the coherence point, never served from a non-coherent cache), the flags likewise, ordered by vmcnt(0) + the
+            // workgroup barrier.  The partner has the same thread -> element map: slot (i * 512 + tid), no layout arithmetic.
+            const int half = mode - 1;
+            if (half) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { const f32x4 t = acc[n][m]; acc[n][m] = acc[n][m + 4]; acc[n][m + 4] = t; }
+            }
+            unsigned long long* wsend = reinterpret_cast<unsigned long long*>(split_ws) + (size_t)(split_idx * 2 + half) * (512 * 32);
+            const unsigned long long* wrecv = reinterpret_cast<const unsigned long long*>(split_ws) + (size_t)(split_idx * 2 + (half ^ 1)) * (512 * 32);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 v = acc[n][4 + m];
+                    unsigned long long* q = wsend + (size_t)((n * 4 + m) * 2) * 512 + tid;
+                    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 512, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's partials have reached the coherence point
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(split_flags + split_idx * 2 + half, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(split_flags + split_idx * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned long long* q = wrecv + (size_t)((n * 4 + m) * 2) * 512 + tid;
+                    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(q + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // K half 0 + K half 1 in that order on both sides of the pair: deterministic and independent of who finalises
+                    const float p0 = __uint_as_float((unsigned)lo), p1 = __uint_as_float((unsigned)(lo >> 32));
+                    const float p2 = __uint_as_float((unsigned)hi), p3 = __uint_as_float((unsigned)(hi >> 32));
+                    if (half) { acc[n][m][0] = p0 + acc[n][m][0]; acc[n][m][1] = p1 + acc[n][m][1]; acc[n][m][2] = p2 + acc[n][m][2]; acc[n][m][3] = p3 + acc[n][m][3]; }
+                    else      { acc[n][m][0] += p0; acc[n][m][1] += p1; acc[n][m][2] += p2; acc[n][m][3] += p3; }
+                }
+            mshift = 4 * half;
+            kpass = 2;
+        }
 
         // Epilogue through the 32 KB C stage in 4 passes of 64 rows (m-tiles 2k, 2k+1 of both wave rows): bias / GELU in registers,
         // bf16 rows staged with the 16-byte chunk XOR-swizzled by the row (the 16 rows a ds_write touches would otherwise share
@@ -494,6 +578,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         unsigned char* sC = reinterpret_cast<unsigned char*>(lds + CST);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if (k >= kpass) break;                            // workgroup-uniform: a split tile's workgroup finalises 4 of its 8 m-tiles
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 const int m = 2 * k + mm;
@@ -513,7 +598,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
-                const int lrow = (prow >> 5) * 128 + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
+                const int lrow = (prow >> 5) * 128 + (2 * k + mshift + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 const int row = cm0 + lrow, col = cn0 + ch * 8;
                 if (row < M && col < N) {
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
@@ -533,7 +618,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 
 template <int EPI>
 static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
-                     int N, int K, hipStream_t st) {
+                     int N, int K, hipStream_t st, GemmSplitWs* sp) {
     const size_t shmem = (size_t)2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     static bool attr_set = false;
     if (!attr_set) {
@@ -551,7 +636,17 @@ static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const f
         n_cu = prop.multiProcessorCount / 8 * 8;
     }
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
-    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles);
+    // split-tail scratch (see the kernel): 4 KB of flags, then one 256 KB accumulator image per pair of workgroups
+    float4* ws = nullptr;
+    int* flags = nullptr;
+    int epoch = 0;
+    if (sp && sp->buf && sp->bytes >= 4096 + (size_t)(grid / 2) * 512 * 32 * 16 && grid / 2 <= 1024 && !getenv("MGEA_BF16_GEMM_NOSPLIT")) {
+        flags = (int*)sp->buf;
+        ws = (float4*)((char*)sp->buf + 4096);
+        epoch = ++sp->epoch;                                               // flags never need clearing: they are compared with the launch's epoch
+    }
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
+                       ws, flags, epoch);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -580,7 +675,7 @@ static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const
 
 template <int EPI>
 static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
-                            int ldc, int M, int N, int K, hipStream_t st) {
+                            int ldc, int M, int N, int K, hipStream_t st, GemmSplitWs* sp) {
     const char* e = getenv("MGEA_BF16_GEMM_TILE");   // 1: 128x128 / 2: 256x128 / 3: 256x256 (tools/gemm_bf16_bench.py)
     const int force = e ? atoi(e) : 0;
     if (force == 1) return launch_glds<EPI, 2, 1>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
@@ -589,21 +684,21 @@ static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, 
     // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
     if (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256))   // the phase-interleaved persistent 256 x 256 kernel
-        return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+        return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
     if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
 }
 
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st) {
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* sp) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
     if (M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && !getenv("MGEA_BF16_GEMM_SMALL")) {
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
         bf16_t* c = (bf16_t*)C;
-        if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
-        if (epi == BEPI_BIAS_GELU) return launch_glds_pick<BEPI_BIAS_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
-        if (epi == BEPI_BIAS_RES && res) return launch_glds_pick<BEPI_BIAS_RES>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+        if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
+        if (epi == BEPI_BIAS_GELU) return launch_glds_pick<BEPI_BIAS_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
+        if (epi == BEPI_BIAS_RES && res) return launch_glds_pick<BEPI_BIAS_RES>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
     }
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
     dim3 grid(tm * tn), block(256);

@@ -75,6 +75,18 @@ int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_de
     return launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream);
 }
 
+int64_t mgea_op_gemm_bf16_scratch_bytes(void) { return (int64_t)MGEA_GEMM_SPLIT_WS_BYTES; }
+
+int mgea_op_gemm_bf16_split(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev, void* out_dev,
+                            int32_t M, int32_t N, int32_t K, int32_t epi, void* scratch_dev, int64_t scratch_bytes,
+                            int32_t* epoch_io, void* stream) {
+    MGEA_REQUIRE(a_dev && w_dev && out_dev && scratch_dev && epoch_io, MGEA_EINVAL, "op_gemm_bf16_split: NULL argument");
+    GemmSplitWs sp{scratch_dev, (size_t)scratch_bytes, *epoch_io};
+    const int rc = launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream, &sp);
+    *epoch_io = sp.epoch;
+    return rc;
+}
+
 int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,
                            int32_t n_head, int32_t head_dim, void* stream) {
     MGEA_REQUIRE(qkv_dev && out_dev, MGEA_EINVAL, "op_attention_bf16: NULL argument");

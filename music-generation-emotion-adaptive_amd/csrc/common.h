@@ -198,8 +198,13 @@ int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int
 // ---- bf16 perf-mode kernels (bf16.hip); bf16 buffers travel as void* ---------------------------
 int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st);
 // C = epi(A @ W^T + bias): epi 0 bias, 1 bias + GELU, 2 bias + residual(res, ld = ldc)
+// Scratch for the persistent bf16 GEMM's split-tail schedule (bf16.hip): 4 KB of flags + one 256 KB fp32 accumulator image per pair
+// of workgroups.  Owned by ONE engine / stream (launches that share it must be stream-ordered); epoch is bumped per launch so the
+// flags never need clearing.  nullptr: every tile is computed whole by one workgroup.
+struct GemmSplitWs { void* buf; size_t bytes; int epoch; };
+constexpr size_t MGEA_GEMM_SPLIT_WS_BYTES = 4096 + (size_t)128 * 512 * 32 * 16;   // up to 256 persistent workgroups
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st);
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* split = nullptr);
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
                               float eps, void* h, int B, int S, int D, int vocab, hipStream_t st);

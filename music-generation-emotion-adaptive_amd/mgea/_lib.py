@@ -71,6 +71,8 @@ PROTOTYPES = {
     "mgea_op_attention_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "mgea_op_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_gemm_bf16_scratch_bytes": (C.c_int64, []),
+    "mgea_op_gemm_bf16_split": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, C.c_int64, C.POINTER(C.c_int32), _P]),
     "mgea_op_attention_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
     "mgea_op_tiled_weight_floats": (C.c_int64, [_I32, _I32]),

@@ -56,9 +56,19 @@ def attention(qkv: torch.Tensor, n_head: int, lens: Optional[torch.Tensor] = Non
     return out
 
 
+class GemmScratch:
+    """Scratch + launch counter for the split-tail schedule of the persistent bf16 GEMM (include/mgea.h); one per stream."""
+
+    def __init__(self, device="cuda"):
+        lib = _lib.load()
+        self.buf = torch.zeros(int(lib.mgea_op_gemm_bf16_scratch_bytes()), dtype=torch.uint8, device=device)
+        self.epoch = C.c_int32(0)
+
+
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-              gelu: bool = False) -> torch.Tensor:
-    """bf16 perf-mode GEMM: (a [M,K] bf16) @ (w [N,K] bf16)^T + bias (fp32) [+GELU | +res (bf16)] -> bf16."""
+              gelu: bool = False, scratch: Optional["GemmScratch"] = None) -> torch.Tensor:
+    """bf16 perf-mode GEMM: (a [M,K] bf16) @ (w [N,K] bf16)^T + bias (fp32) [+GELU | +res (bf16)] -> bf16.
+    scratch: let the persistent kernel split its left-over tiles across two workgroups (what BertEngine does)."""
     lib = _lib.load()
     a, w = _dev(a.to(torch.bfloat16)), _dev(w.to(torch.bfloat16))
     M, K = a.shape
@@ -67,6 +77,10 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     b = None if bias is None else _dev(bias.float())
     r = None if res is None else _dev(res.to(torch.bfloat16))
     epi = 2 if res is not None else (1 if gelu else 0)
+    if scratch is not None:
+        check(lib.mgea_op_gemm_bf16_split(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, ptr(scratch.buf),
+                                          scratch.buf.numel(), C.byref(scratch.epoch), stream_ptr()))
+        return out
     check(lib.mgea_op_gemm_bf16(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, stream_ptr()))
     return out
 

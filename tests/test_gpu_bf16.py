@@ -60,6 +60,45 @@ def test_gemm_bf16_phase_interleaved_kernel(M, N, K, mode, monkeypatch):
         assert float((err / (want.abs() + 1.0)).max()) < 6e-3
 
 
+@pytest.mark.parametrize("N,K,mode", [(768, 768, "res"), (768, 3072, "res"), (768, 768, "bias"), (2304, 768, "bias")])
+def test_gemm_bf16_split_tail_schedule(N, K, mode):
+    """DistilBERT's N = 768 projections at the bench shape (M = 32768) are 384 tiles of 256 x 256 on 256 CUs: with the engine's
+    scratch and K >= 2048 the persistent kernel shares each of the 128 left-over tiles between two workgroups (one per half of K;
+    they swap half of their fp32 partial sums through the scratch with agent-scope relaxed atomics and finalise half the tile
+    each).  Checked against the same kernel without scratch (every tile whole) -- the two differ only by where the fp32 sum over
+    K is cut, i.e. by fp32 rounding before the bf16 output rounding -- and against torch's fp32 matmul of the same bf16 inputs on
+    the GPU (fp64 on the CPU would take minutes at this size); launched three times on one scratch: the flags are epoch-tagged
+    and never cleared.  The K = 768 shapes (and N = 2304: 4.5 rounds) take the scratch but keep whole tiles: must be identical."""
+    from mgea import ops
+    M = 32768
+    a = rnd(M, K, seed=21).bfloat16().cuda()
+    w = rnd(N, K, seed=22, scale=K ** -0.5).bfloat16().cuda()
+    b = rnd(N, seed=23).cuda()
+    r = rnd(M, N, seed=24).bfloat16().cuda()
+    want = a.float() @ w.float().t() + b
+    if mode == "res":
+        want = want + r.float()
+    whole = ops.gemm_bf16(a, w, b, r if mode == "res" else None)
+    sc = ops.GemmScratch()
+    outs = [ops.gemm_bf16(a, w, b, r if mode == "res" else None, scratch=sc) for _ in range(3)]
+    assert sc.epoch.value == 3
+    for got in outs:
+        assert torch.equal(got, outs[0])                        # deterministic: own half + partner's half, always in that order
+        err = (got.float() - want).abs() / (want.abs() + 1.0)
+        assert float(err.max()) < 6e-3
+    # one bf16 ulp at most between the two schedules, and only on the tiles that were split
+    d = (outs[0].float() - whole.float()).abs() / (whole.float().abs() + 1.0)
+    assert float(d.max()) < 8e-3
+    assert float((d > 0).float().mean()) < 0.2
+    if K < 2048:
+        assert torch.equal(outs[0], whole)
+    else:
+        # 384 tiles in 8 runs of 48 (one per XCD): the first 32 of a run are whole tiles, the last 16 are shared
+        t = torch.arange(384, device="cuda").reshape(128, 3)
+        shared = ((t % 48) >= 32).repeat_interleave(256, 0).repeat_interleave(256, 1)
+        assert bool((d[~shared] == 0).all()) and bool((d[shared] > 0).any())
+
+
 def test_layernorm_bf16():
     from mgea import ops
     x, w, b = rnd(300, 768, seed=1, scale=3.0).bfloat16(), rnd(768, seed=2) + 1.0, rnd(768, seed=3)
