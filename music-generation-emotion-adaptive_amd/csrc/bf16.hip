@@ -341,11 +341,13 @@ __device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned voff
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
+typedef unsigned long long u64x1;
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                           bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
-                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch) {
+                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch, int split_min_kt) {
     constexpr int BM = 256, BN = 256;
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;     // in 16-byte chunks: A tile, then the W tile
     constexpr int CST = 2 * STAGE;                         // the epilogue's own 32 KB behind the two operand stages
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
     // saves 0.75 us per K-tile: worth it from K = 2048 on (measured, tools/gemm_bf16_bench.py: K = 3072 167 -> 148 us, K = 768
     // 60 -> 63 and 124 -> 135 us), so K = 768 keeps its whole tiles.
     const int full_rounds = per_x > 0 ? per_x / wg_x : 0, rem = per_x > 0 ? per_x - full_rounds * wg_x : 0;
-    const bool split = split_ws && rem > 0 && 2 * rem <= wg_x && KT >= 32;
+    const bool split = split_ws && rem > 0 && 2 * rem <= wg_x && KT >= split_min_kt;
     int u_tile = 0, u_kt0 = 0, u_nkt = 0, u_mode = 0;       // mode 0: whole tile, 1 / 2: first / second half of K of a shared tile
     auto get_unit = [&](int ui) -> bool {                   // the ui-th unit of this workgroup
         if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_kt0 = 0; u_nkt = KT; u_mode = 0; return true; }
@@ -554,19 +556,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                     __builtin_amdgcn_s_sleep(8);
             }
             __syncthreads();
+            // Receive in two batches of 8 x 16 bytes, each behind ONE wait.  As relaxed atomics hipcc waits for every load before it
+            // issues the next (64 round trips in a row: most of the exchange's first cost of 15-20 us); the loads are therefore plain
+            // `global_load_dwordx4 ... sc1` from inline asm (same cache policy as the agent-scope atomic: read at the coherence point),
+            // and the wait names the destination registers as read-write operands so that nothing can touch them before it.
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; n += 2) {
+                f32x4 pv[2][4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const unsigned long long* q = wrecv + (size_t)((n * 4 + m) * 2) * 512 + tid;
-                    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long hi = __hip_atomic_load(q + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // K half 0 + K half 1 in that order on both sides of the pair: deterministic and independent of who finalises
-                    const float p0 = __uint_as_float((unsigned)lo), p1 = __uint_as_float((unsigned)(lo >> 32));
-                    const float p2 = __uint_as_float((unsigned)hi), p3 = __uint_as_float((unsigned)(hi >> 32));
-                    if (half) { acc[n][m][0] = p0 + acc[n][m][0]; acc[n][m][1] = p1 + acc[n][m][1]; acc[n][m][2] = p2 + acc[n][m][2]; acc[n][m][3] = p3 + acc[n][m][3]; }
-                    else      { acc[n][m][0] += p0; acc[n][m][1] += p1; acc[n][m][2] += p2; acc[n][m][3] += p3; }
-                }
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        // slot layout of the sender: 64-bit pairs (2 i) * 512 + tid and (2 i + 1) * 512 + tid -> two 8-byte halves, not
+                        // one 16-byte unit: two dwordx2 loads into the halves of one register quad
+                        const unsigned long long* q = wrecv + (size_t)(((n + nn) * 4 + m) * 2) * 512 + tid + 256;   // +-2048 B: 13-bit offsets
+                        asm volatile("global_load_dwordx2 %0, %2, off offset:-2048 sc1\n\tglobal_load_dwordx2 %1, %2, off offset:2048 sc1"
+                                     : "=&v"(*reinterpret_cast<u64x1*>(&pv[nn][m])), "=&v"(*(reinterpret_cast<u64x1*>(&pv[nn][m]) + 1)) : "v"(q) : "memory");
+                    }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(pv[0][0]), "+v"(pv[0][1]), "+v"(pv[0][2]), "+v"(pv[0][3]), "+v"(pv[1][0]), "+v"(pv[1][1]), "+v"(pv[1][2]), "+v"(pv[1][3])
+                             :: "memory");
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[n + nn][m] += pv[nn][m];   // (a + b == b + a bitwise: the order of the K halves does not matter)
+            }
             mshift = 4 * half;
             kpass = 2;
         }
@@ -576,6 +590,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual is added on the way
         // out.  Raw barriers + lgkmcnt only: a __syncthreads() would wait for the DMAs just issued.
         unsigned char* sC = reinterpret_cast<unsigned char*>(lds + CST);
+        // Residual rows one pass ahead: loaded where they are used, behind the pass's barrier, every pass of every workgroup sat
+        // through a load round trip in the middle of the chip-wide store burst (FC2: 34 of 168 us were residual loads + stores).
+        bf16x8 rnext[4];
+        auto load_res = [&](int k, int ms) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
+                const int lrow = (prow >> 5) * 128 + (2 * k + ms + ((prow >> 4) & 1)) * 16 + (prow & 15);
+                int row = cm0 + lrow, col = cn0 + ch * 8;
+                row = row < M ? row : M - 1; col = col < N ? col : 0;         // clamped: loaded, not used
+                rnext[i] = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+            }
+        };
+        if (EPI == BEPI_BIAS_RES && kpass > 0) load_res(0, mshift);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= kpass) break;                            // workgroup-uniform: a split tile's workgroup finalises 4 of its 8 m-tiles
@@ -595,6 +623,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            bf16x8 rcur[4];
+            if (EPI == BEPI_BIAS_RES) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
+                if (k + 1 < kpass) load_res(k + 1, mshift);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
@@ -603,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 if (row < M && col < N) {
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
                     if (EPI == BEPI_BIAS_RES) {
-                        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+                        const bf16x8 r8 = rcur[i];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
                     }
@@ -637,6 +671,7 @@ static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const f
     }
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
     // split-tail scratch (see the kernel): 4 KB of flags, then one 256 KB accumulator image per pair of workgroups
+    static const int split_min_kt = getenv("MGEA_BF16_GEMM_SPLIT_MIN_KT") ? atoi(getenv("MGEA_BF16_GEMM_SPLIT_MIN_KT")) : 32;   // K >= 2048 (A/B hook)
     float4* ws = nullptr;
     int* flags = nullptr;
     int epoch = 0;
@@ -646,7 +681,7 @@ static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const f
         epoch = ++sp->epoch;                                               // flags never need clearing: they are compared with the launch's epoch
     }
     hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
-                       ws, flags, epoch);
+                       ws, flags, epoch, split_min_kt);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
