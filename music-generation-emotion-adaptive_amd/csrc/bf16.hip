@@ -42,17 +42,41 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2 };
 
-// erf-GELU for bf16 outputs: erf from Abramowitz & Stegun 7.1.25 (|error| < 2.5e-5, far below the 2^-9 rounding of the bf16
-// result), t = 1 / (1 + p z) by v_rcp_f32 and exp(-z^2) by one v_exp_f32 (2^x): 12 VALU instructions per element.  The
-// 7.1.26 form with a full-precision division and libm-style exp cost ~40, i.e. ~14 us of a 40 us FC1 tile round.
+// erf-GELU for bf16 outputs with ONE transcendental.  With a = |x|: gelu(x) = max(x, 0) - 0.5 a erfc(a / sqrt 2), and
+// erfc(a / sqrt 2) = 2^q(a) where q = log2(erfcx) - (a^2 / 2) log2 e is smooth: a degree-5 polynomial (weighted least squares on
+// [0, 6.5], fitted and checked in fp32 against scipy's erf: |gelu error| < 1.5e-5 on [-12, 12], far below the 2^-9 rounding of the
+// bf16 result; beyond 6.5 the clamped tail is < 2^-30).  11 instructions per element, v_exp_f32 the only quarter-rate one.  History:
+// A&S 7.1.26 with a full-precision division and libm-style exp cost ~40 (14 us of a 40 us FC1 tile round); A&S 7.1.25 on
+// v_rcp_f32 + v_exp_f32 12 with two transcendentals, still 28 of FC1's 169 us (measured by switching GELU off).
+#define MGEA_GELU_D0 -1.585257735e-05f
+#define MGEA_GELU_D1 -1.150631181e+00f
+#define MGEA_GELU_D2 -4.612153958e-01f
+#define MGEA_GELU_D3 -4.992833406e-02f
+#define MGEA_GELU_D4 6.105210696e-03f
+#define MGEA_GELU_D5 -3.249367875e-04f
+#define MGEA_GELU_AMAX 6.505382387f
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    return 0.5f * fmaf(ax, erf_abs, x);      // 0.5 x (1 + sign(x) erf|.|) = 0.5 (x + |x| erf|.|)
+    const float a = fminf(fabsf(x), MGEA_GELU_AMAX);
+    float q = fmaf(MGEA_GELU_D5, a, MGEA_GELU_D4);
+    q = fmaf(q, a, MGEA_GELU_D3);
+    q = fmaf(q, a, MGEA_GELU_D2);
+    q = fmaf(q, a, MGEA_GELU_D1);
+    q = fmaf(q, a, MGEA_GELU_D0);
+    return fmaf(-0.5f * a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
+// Two elements with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two results per instruction).  For epilogues only --
+// beside MFMAs packed fp32 is slower than scalar (MI355X_MICROARCH.md).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 a = {fminf(fabsf(x[0]), MGEA_GELU_AMAX), fminf(fabsf(x[1]), MGEA_GELU_AMAX)};
+    f32x2 q = __builtin_elementwise_fma((f32x2){MGEA_GELU_D5, MGEA_GELU_D5}, a, (f32x2){MGEA_GELU_D4, MGEA_GELU_D4});
+    q = __builtin_elementwise_fma(q, a, (f32x2){MGEA_GELU_D3, MGEA_GELU_D3});
+    q = __builtin_elementwise_fma(q, a, (f32x2){MGEA_GELU_D2, MGEA_GELU_D2});
+    q = __builtin_elementwise_fma(q, a, (f32x2){MGEA_GELU_D1, MGEA_GELU_D1});
+    q = __builtin_elementwise_fma(q, a, (f32x2){MGEA_GELU_D0, MGEA_GELU_D0});
+    const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 pos = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return __builtin_elementwise_fma(a * -0.5f, e, pos);
 }
 
 template <int EPI>
@@ -615,7 +639,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 for (int n = 0; n < 4; ++n) {
                     const int lcol = wn * 64 + n * 16 + 4 * g;
                     float4 v = add4(make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]), bv[n]);
-                    if (EPI == BEPI_BIAS_GELU) v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+                    if (EPI == BEPI_BIAS_GELU) {
+                        const f32x2 g0 = gelu_fast2((f32x2){v.x, v.y}), g1 = gelu_fast2((f32x2){v.z, v.w});
+                        v = make_float4(g0[0], g0[1], g1[0], g1[1]);
+                    }
                     bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
                     const int ch = (lcol >> 3) ^ (prow & 31);
                     *reinterpret_cast<bf16x4*>(sC + prow * 512 + ch * 16 + (lcol & 7) * 2) = o;
