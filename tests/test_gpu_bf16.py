@@ -107,7 +107,7 @@ def test_layernorm_bf16():
     assert float((got.double() - want).abs().max()) < 3e-2
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 128, 12), (3, 24, 2), (1, 200, 4), (2, 64, 8)])
+@pytest.mark.parametrize("B,T,H", [(2, 128, 12), (3, 24, 2), (1, 200, 4), (2, 64, 8), (1, 1, 1), (2, 129, 3), (5, 513, 1)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_bf16(B, T, H, masked):
     from mgea import ops
