@@ -65,6 +65,15 @@ struct mgea_bert {
           *pooled2 = nullptr;
     void *wb = nullptr, *hb = nullptr, *qkvb = nullptr, *ctxb = nullptr, *ffnb = nullptr, *tmpb = nullptr;  // bf16 mode
     GemmSplitWs split{nullptr, 0, 0};                        // bf16 mode: scratch of the persistent GEMM's split-tail schedule
+    // bf16 mode, folded-LayerNorm pipeline (big batches: every GEMM on the persistent kernel): W diag(gamma) copies, c1 / c2 vectors,
+    // per-tile row sums and the two (mean, rstd) tables
+    void* wfold = nullptr;
+    float *fvec = nullptr, *stats_part = nullptr, *rowstat_sa = nullptr, *rowstat_out = nullptr;
+    float* ident = nullptr;                                  // [M][2] (0, 1) rows, then D ones, then D zeros: the identity LayerNorm of layer 0's residual
+    const char* fc1f(int l) const { return (const char*)wfold + (int64_t)l * cfg.hidden * cfg.dim * 2; }
+    const char* qkvf(int l) const { return (const char*)wfold + ((int64_t)cfg.n_layers * cfg.hidden + (int64_t)(l - 1) * 3 * cfg.dim) * cfg.dim * 2; }
+    float* fc1c(int l, int which) const { return fvec + ((int64_t)l * 2 + which) * cfg.hidden; }
+    float* qkvc(int l, int which) const { return fvec + (int64_t)cfg.n_layers * 2 * cfg.hidden + ((int64_t)(l - 1) * 2 + which) * 3 * cfg.dim; }
     const char* wbf(int64_t off_floats) const { return (const char*)wb + off_floats * 2; }
     int64_t slab_cap = 0;
     const float* w(int i) const { return arena + off[i]; }
@@ -90,7 +99,7 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_destroy(mgea_bert* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->split.buf};
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->split.buf, h->wfold, h->fvec, h->stats_part, h->rowstat_sa, h->rowstat_out, h->ident};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;
@@ -132,6 +141,28 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
              hipMemset(h->split.buf, 0, 4096) == hipSuccess;                       // the flags; epochs start at 1
         if (ok) h->split.bytes = MGEA_GEMM_SPLIT_WS_BYTES;
         if (ok) ok = launch_f32_to_bf16(arena_dev, h->wb, total, nullptr) == MGEA_OK && hipDeviceSynchronize() == hipSuccess;
+        if (ok) {   // folded-LayerNorm pipeline (see mgea_bert_forward): FC1 of every layer, QKV of layers >= 1
+            const int64_t L = cfg->n_layers;
+            const int64_t wel = (L * Hd + (L - 1) * 3 * D) * D, vel = L * 2 * Hd + (L - 1) * 2 * 3 * D;
+            ok = hipMalloc(&h->wfold, wel * 2) == hipSuccess && hipMalloc((void**)&h->fvec, (vel > 0 ? vel : 1) * 4) == hipSuccess &&
+                 hipMalloc((void**)&h->stats_part, M * ((D + 255) / 256) * 2 * 4) == hipSuccess &&
+                 hipMalloc((void**)&h->rowstat_sa, M * 2 * 4) == hipSuccess && hipMalloc((void**)&h->rowstat_out, M * 2 * 4) == hipSuccess &&
+                 hipMalloc((void**)&h->ident, (M * 2 + 2 * D) * 4) == hipSuccess;
+            if (ok) {
+                std::vector<float> idv((size_t)(M * 2 + 2 * D), 0.f);
+                for (int64_t r = 0; r < M; ++r) idv[(size_t)r * 2 + 1] = 1.f;
+                for (int64_t d = 0; d < D; ++d) idv[(size_t)(M * 2 + d)] = 1.f;
+                ok = hipMemcpy(h->ident, idv.data(), idv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+            }
+            for (int l = 0; ok && l < L; ++l) {
+                ok = launch_fold_ln_weights_bf16(h->lw(l, BL_L1W), h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->lw(l, BL_L1B), (void*)h->fc1f(l),
+                                                 h->fc1c(l, 0), h->fc1c(l, 1), (int)Hd, (int)D, nullptr) == MGEA_OK;
+                if (ok && l >= 1)
+                    ok = launch_fold_ln_weights_bf16(h->lw(l, BL_QKVW), h->lw(l - 1, BL_OLNW), h->lw(l - 1, BL_OLNB), h->lw(l, BL_QKVB),
+                                                     (void*)h->qkvf(l), h->qkvc(l, 0), h->qkvc(l, 1), (int)(3 * D), (int)D, nullptr) == MGEA_OK;
+            }
+            if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+        }
     } else {
         ok = hipMalloc((void**)&h->h, M * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, M * 3 * D * 4) == hipSuccess &&
              hipMalloc((void**)&h->ctx, M * D * 4) == hipSuccess && hipMalloc((void**)&h->ffn, M * Hd * 4) == hipSuccess &&
@@ -171,6 +202,42 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         auto wb = [&](int l, int j) { return (const void*)h->wbf(h->off[B_HEAD0 + l * BL_COUNT + j]); };
         MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
                                            S, D, c.vocab, st));
+        // Folded-LayerNorm pipeline: when every GEMM of a layer runs on the persistent 256 x 256 kernel (big batches), no LayerNorm
+        // kernel runs at all.  The residual GEMMs write the RAW sums (x + sublayer(x)) and per-tile row sums; a 1-launch reduction
+        // turns those into (mean, rstd) per row; the consumers apply the LayerNorm themselves: the next GEMM as rstd (A W'^T - mean
+        // c1) + c2 with W' = W diag(gamma) (epilogues 3 / 4), the next residual GEMM by normalising the residual row on the way in
+        // (epilogue 5), the classifier head on its B CLS rows.  Saves a read + write of [M, D] per LayerNorm (12 x 20 us at the bench
+        // shape).  hb and tmpb alternate as the raw buffers; layer 0 starts from the materialised embedding LayerNorm.
+        const bool nofold = getenv("MGEA_BERT_BF16_NOFOLD") != nullptr;   // A/B and tests
+        const bool fold = !nofold && D % 256 == 0 && Hd % 256 == 0 && gemm_bf16_is_persistent(M, 3 * D, D) && gemm_bf16_is_persistent(M, D, D) &&
+                          gemm_bf16_is_persistent(M, Hd, D) && gemm_bf16_is_persistent(M, D, Hd);
+        if (fold) {
+            const int npart = D / 256;
+            const float *id_g = h->ident + (int64_t)c.max_tokens * 2, *id_b = id_g + D;
+            for (int l = 0; l < c.n_layers; ++l) {
+                const bool first = l == 0;
+                if (first) {
+                    MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st, &h->split));
+                } else {
+                    BfEpiLn q{h->rowstat_out, h->qkvc(l, 0), nullptr, nullptr, nullptr};
+                    MGEA_TRY(launch_gemm_bf16(h->hb, D, h->qkvf(l), D, h->qkvc(l, 1), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 3, st, &h->split, &q));
+                }
+                MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
+                // out-proj + LayerNorm_out(l-1)(raw hb) as the residual (layer 0: hb is already normalised) -> raw tmpb + row sums
+                BfEpiLn o{first ? h->ident : h->rowstat_out, nullptr, first ? id_g : h->lw(l - 1, BL_OLNW), first ? id_b : h->lw(l - 1, BL_OLNB),
+                          h->stats_part};
+                MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 5, st, &h->split, &o));
+                MGEA_TRY(launch_ln_rowstat(h->stats_part, h->rowstat_sa, M, npart, D, c.ln_eps, st));
+                BfEpiLn f1{h->rowstat_sa, h->fc1c(l, 0), nullptr, nullptr, nullptr};
+                MGEA_TRY(launch_gemm_bf16(h->tmpb, D, h->fc1f(l), D, h->fc1c(l, 1), nullptr, h->ffnb, Hd, M, Hd, D, 4, st, &h->split, &f1));
+                // FC2 + LayerNorm_sa(l)(raw tmpb) as the residual -> raw hb + row sums
+                BfEpiLn f2{h->rowstat_sa, nullptr, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->stats_part};
+                MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->tmpb, h->hb, D, M, D, Hd, 5, st, &h->split, &f2));
+                MGEA_TRY(launch_ln_rowstat(h->stats_part, h->rowstat_out, M, npart, D, c.ln_eps, st));
+            }
+            MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(c.n_layers - 1, BL_OLNW), h->lw(c.n_layers - 1, BL_OLNB), h->pooled, B, S,
+                                               D, st));
+        } else {
         for (int l = 0; l < c.n_layers; ++l) {
             MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st, &h->split));
             MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
@@ -181,6 +248,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
         }
         MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+        }
     } else {
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
                                   D, c.vocab, st));

@@ -40,7 +40,11 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2 };
+enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2,
+       // LayerNorm folded around the GEMMs (persistent 256 x 256 kernel only; see BfEpiLn in common.h):
+       BEPI_LNFOLD = 3,        // out = rstd_row (A W'^T - mean_row c1) + c2         (A = raw rows, W' = W diag(gamma), c2 in the bias slot)
+       BEPI_LNFOLD_GELU = 4,   // ... then GELU
+       BEPI_RES_LN = 5 };      // out = A W^T + bias + LN(res rows) (LayerNorm of the residual applied on the way in), + row statistics of out
 
 // erf-GELU for bf16 outputs with ONE transcendental.  With a = |x|: gelu(x) = max(x, 0) - 0.5 a erfc(a / sqrt 2), and
 // erfc(a / sqrt 2) = 2^q(a) where q = log2(erfcx) - (a^2 / 2) log2 e is smooth: a degree-5 polynomial (weighted least squares on
@@ -367,12 +371,24 @@ __device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned voff
 
 typedef unsigned long long u64x1;
 
+// Sum over the 32 lanes of a half wave (lanes 32 h .. 32 h + 31), result in all of them: four DPP row rotations (VALU speed) give
+// the 16-lane sums, one ds_bpermute adds the neighbouring row.  (Five __shfl_xor steps = five trips through the LDS pipeline per
+// value: 160 of them per tile made the statistics cost more than the LayerNorm kernel they replace.)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#define MGEA_ROR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    MGEA_ROR_ADD(1); MGEA_ROR_ADD(2); MGEA_ROR_ADD(4); MGEA_ROR_ADD(8);
+#undef MGEA_ROR_ADD
+    return v + __shfl_xor(v, 16, 64);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                           bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
-                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch, int split_min_kt) {
+                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch, int split_min_kt, BfEpiLn ln) {
     constexpr int BM = 256, BN = 256;
+    constexpr bool LNF = EPI == BEPI_LNFOLD || EPI == BEPI_LNFOLD_GELU;
+    constexpr bool RESV = EPI == BEPI_BIAS_RES || EPI == BEPI_RES_LN;
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;     // in 16-byte chunks: A tile, then the W tile
     constexpr int CST = 2 * STAGE;                         // the epilogue's own 32 KB behind the two operand stages
     extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [2][STAGE] + [2048] = 160 KB; all LDS in this one array
@@ -614,9 +630,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual is added on the way
         // out.  Raw barriers + lgkmcnt only: a __syncthreads() would wait for the DMAs just issued.
         unsigned char* sC = reinterpret_cast<unsigned char*>(lds + CST);
+        // LayerNorm folded into this GEMM (LNF): this lane's rows' (mean, rstd) and its columns' c1 = sum_k W'[n, k]
+        float mu[8], rs[8];
+        float4 c1v[4];
+        if (LNF) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                int row = cm0 + wm * 128 + (m + mshift) * 16 + c;
+                row = row < M ? row : M - 1;
+                const float2 st = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
+                mu[m] = st.x; rs[m] = st.y;
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = cn0 + wn * 64 + n * 16 + 4 * g;
+                c1v[n] = col < N ? ld4(ln.c1 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         // Residual rows one pass ahead: loaded where they are used, behind the pass's barrier, every pass of every workgroup sat
         // through a load round trip in the middle of the chip-wide store burst (FC2: 34 of 168 us were residual loads + stores).
+        // RES_LN: the residual is LayerNorm(res row) -- the raw row comes with its (mean, rstd), gamma / beta of this thread's 8
+        // columns are loaded once per tile (a thread keeps its 16-byte chunk index through all passes).
         bf16x8 rnext[4];
+        float2 snext[4];
+        const int my_col = cn0 + (tid & 31) * 8;
+        // (unconditional loads: a load behind a run-time branch makes hipcc wait vmcnt(0) right after it, which put a full round trip
+        // into every pass; an already-normalised residual therefore comes with an identity table: mean 0, rstd 1, gamma 1, beta 0.
+        // N % 256 == 0 for this epilogue, so the 8 columns are always in range)
+        float4 gam0, gam1, bet0, bet1;
+        if (EPI == BEPI_RES_LN) {
+            gam0 = ld4(ln.ln_g + my_col); gam1 = ld4(ln.ln_g + my_col + 4);
+            bet0 = ld4(ln.ln_b + my_col); bet1 = ld4(ln.ln_b + my_col + 4);
+        }
         auto load_res = [&](int k, int ms) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -625,9 +670,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 int row = cm0 + lrow, col = cn0 + ch * 8;
                 row = row < M ? row : M - 1; col = col < N ? col : 0;         // clamped: loaded, not used
                 rnext[i] = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+                if (EPI == BEPI_RES_LN) snext[i] = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
             }
         };
-        if (EPI == BEPI_BIAS_RES && kpass > 0) load_res(0, mshift);
+        if (RESV && kpass > 0) load_res(0, mshift);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= kpass) break;                            // workgroup-uniform: a split tile's workgroup finalises 4 of its 8 m-tiles
@@ -638,8 +684,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int lcol = wn * 64 + n * 16 + 4 * g;
-                    float4 v = add4(make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]), bv[n]);
-                    if (EPI == BEPI_BIAS_GELU) {
+                    float4 v = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+                    if (LNF)   // rstd (A W'^T - mean c1) + c2, c2 in the bias slot
+                        v = make_float4(rs[m] * fmaf(-mu[m], c1v[n].x, v.x), rs[m] * fmaf(-mu[m], c1v[n].y, v.y),
+                                        rs[m] * fmaf(-mu[m], c1v[n].z, v.z), rs[m] * fmaf(-mu[m], c1v[n].w, v.w));
+                    v = add4(v, bv[n]);
+                    if (EPI == BEPI_BIAS_GELU || EPI == BEPI_LNFOLD_GELU) {
                         const f32x2 g0 = gelu_fast2((f32x2){v.x, v.y}), g1 = gelu_fast2((f32x2){v.z, v.w});
                         v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     }
@@ -651,9 +701,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             bf16x8 rcur[4];
-            if (EPI == BEPI_BIAS_RES) {
+            float2 scur[4];
+            if (RESV) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
+                for (int i = 0; i < 4; ++i) { rcur[i] = rnext[i]; scur[i] = snext[i]; }
                 if (k + 1 < kpass) load_res(k + 1, mshift);
             }
 #pragma unroll
@@ -661,14 +712,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
                 const int lrow = (prow >> 5) * 128 + (2 * k + mshift + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 const int row = cm0 + lrow, col = cn0 + ch * 8;
-                if (row < M && col < N) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
-                    if (EPI == BEPI_BIAS_RES) {
-                        const bf16x8 r8 = rcur[i];
+                const bool inb = row < M && col < N;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
+                if (RESV) {
+                    const bf16x8 r8 = rcur[i];
+                    const float gam[8] = {gam0.x, gam0.y, gam0.z, gam0.w, gam1.x, gam1.y, gam1.z, gam1.w};
+                    const float bet[8] = {bet0.x, bet0.y, bet0.z, bet0.w, bet1.x, bet1.y, bet1.z, bet1.w};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)r8[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        float r = (float)r8[j];
+                        if (EPI == BEPI_RES_LN) r = fmaf((r - scur[i].x) * scur[i].y, gam[j], bet[j]);   // LayerNorm of the residual row
+                        v[j] = (bf16_t)((float)v[j] + r);
                     }
-                    *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+                }
+                if (inb) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+                if (EPI == BEPI_RES_LN && ln.stats_out) {
+                    // (sum, sum of squares) of the row's 256 bf16 outputs in this tile: the row's 32 chunks sit in 32 consecutive lanes
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float x = (inb && col + j < N) ? (float)v[j] : 0.f; s1 += x; s2 = fmaf(x, x, s2); }
+                    s1 = half_wave_sum(s1);
+                    s2 = half_wave_sum(s2);
+                    if (ch == 0 && row < M)
+                        *reinterpret_cast<float2*>(ln.stats_out + ((int64_t)row * tiles_n + (cn0 >> 8)) * 2) = make_float2(s1, s2);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -679,7 +745,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 
 template <int EPI>
 static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
-                     int N, int K, hipStream_t st, GemmSplitWs* sp) {
+                     int N, int K, hipStream_t st, GemmSplitWs* sp, const BfEpiLn* lnp = nullptr) {
     const size_t shmem = (size_t)2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     static bool attr_set = false;
     if (!attr_set) {
@@ -708,7 +774,7 @@ static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const f
         epoch = ++sp->epoch;                                               // flags never need clearing: they are compared with the launch's epoch
     }
     hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
-                       ws, flags, epoch, split_min_kt);
+                       ws, flags, epoch, split_min_kt, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -751,10 +817,33 @@ static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, 
     return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
 }
 
+bool gemm_bf16_is_persistent(int M, int N, int K) {
+    const char* e = getenv("MGEA_BF16_GEMM_TILE");
+    const int force = e ? atoi(e) : 0;
+    if (!(M >= 512 && N >= 128 && N % 8 == 0 && K % 64 == 0) || getenv("MGEA_BF16_GEMM_SMALL")) return false;
+    const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
+    return force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256);
+}
+
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* sp) {
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* sp, const BfEpiLn* lnp) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
+    if (epi >= BEPI_LNFOLD) {   // LayerNorm folded around the GEMM: the persistent kernel only
+        MGEA_REQUIRE(epi <= BEPI_RES_LN && lnp && bias, MGEA_EINVAL, "bf16 gemm: epilogue %d needs its LayerNorm operands and a bias / c2 vector", epi);
+        MGEA_REQUIRE(gemm_bf16_is_persistent(M, N, K) && ldc % 8 == 0 && N % 256 == 0, MGEA_EINVAL,
+                     "bf16 gemm: epilogue %d exists on the persistent 256 x 256 kernel only (M=%d N=%d K=%d)", epi, M, N, K);
+        const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
+        bf16_t* c = (bf16_t*)C;
+        if (epi == BEPI_RES_LN) {
+            MGEA_REQUIRE(res && lnp->rowstat && lnp->ln_g && lnp->ln_b, MGEA_EINVAL,
+                         "bf16 gemm: RES_LN without residual / row statistics / gamma / beta (identity tables for a normalised residual)");
+            return launch_ph<BEPI_RES_LN>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
+        }
+        MGEA_REQUIRE(lnp->rowstat && lnp->c1, MGEA_EINVAL, "bf16 gemm: LNFOLD without row statistics / c1");
+        if (epi == BEPI_LNFOLD) return launch_ph<BEPI_LNFOLD>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
+        return launch_ph<BEPI_LNFOLD_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
+    }
     if (M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && !getenv("MGEA_BF16_GEMM_SMALL")) {
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
         bf16_t* c = (bf16_t*)C;
@@ -775,6 +864,73 @@ int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
             break;
         default: MGEA_REQUIRE(false, MGEA_EINVAL, "bf16 gemm: bad epilogue %d", epi);
     }
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Helpers of the folded-LayerNorm pipeline (BfEpiLn).
+// (mean, rstd) per row from the per-tile (sum, sum of squares) the RES_LN epilogue left; the last subtraction in double.
+// A launch of its own (5 us): deriving the statistics inside the consumers instead (8-16 more loaded values live per lane in their
+// epilogues) pushed 20-50 registers of the persistent kernel to scratch and cost 0.45 ms per forward.
+__global__ void ln_rowstat_kernel(const float* __restrict__ part, float* __restrict__ rowstat, int M, int n_part, int C, float eps) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n_part; ++i) { s1 += part[((int64_t)row * n_part + i) * 2]; s2 += part[((int64_t)row * n_part + i) * 2 + 1]; }
+    const double mean = s1 / C;
+    double var = s2 / C - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    rowstat[(int64_t)row * 2] = (float)mean;
+    rowstat[(int64_t)row * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(ln_rowstat_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, part, rowstat, M, n_part, C, eps);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// W' = bf16(W diag(gamma)), c1[n] = sum_k W'[n, k] (of the ROUNDED folded weights: the epilogue subtracts exactly what the MFMAs
+// added), c2[n] = b[n] + sum_k W[n, k] beta[k].  One workgroup per output row n.
+__global__ __launch_bounds__(256) void fold_ln_weights_bf16_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ b,
+                                                                  bf16_t* __restrict__ Wf, float* __restrict__ c1,
+                                                                  float* __restrict__ c2, int K) {
+    const int64_t n = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[n * K + k];
+        const bf16_t wf = (bf16_t)(w * gamma[k]);
+        Wf[n * K + k] = wf;
+        s1 += (float)wf;
+        s2 = fmaf(w, beta[k], s2);
+    }
+    __shared__ float r1[4], r2[4];
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1[n] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        c2[n] = b[n] + ((r2[0] + r2[1]) + (r2[2] + r2[3]));
+    }
+}
+int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float* beta, const float* b, void* Wf, float* c1, float* c2,
+                                int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fold_ln_weights_bf16_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, b, (bf16_t*)Wf, c1, c2, K);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// CLS rows (row b * S) of the RAW last-layer output -> LayerNorm with the row's (mean, rstd) -> fp32 [B, D]
+__global__ void gather_cls_ln_bf16_kernel(const bf16_t* __restrict__ h, const float* __restrict__ rowstat, const float* __restrict__ g,
+                                          const float* __restrict__ be, float* __restrict__ out, int S, int D) {
+    const int64_t row = (int64_t)blockIdx.x * S;
+    const float mean = rowstat[row * 2], rstd = rowstat[row * 2 + 1];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[(int64_t)blockIdx.x * D + d] = fmaf(((float)h[row * D + d] - mean) * rstd, g[d], be[d]);
+}
+int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* g, const float* be, float* out, int B, int S, int D,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(gather_cls_ln_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, rowstat, g, be, out, S, D);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

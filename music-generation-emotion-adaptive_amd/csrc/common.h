@@ -198,13 +198,28 @@ int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int
 // ---- bf16 perf-mode kernels (bf16.hip); bf16 buffers travel as void* ---------------------------
 int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st);
 // C = epi(A @ W^T + bias): epi 0 bias, 1 bias + GELU, 2 bias + residual(res, ld = ldc)
+// LayerNorm folded around the bf16 GEMMs (bf16.hip, epilogues 3-5 of launch_gemm_bf16; persistent 256 x 256 kernel only).
+//   epi 3 / 4 (LNFOLD / +GELU): A = RAW rows, W = W diag(gamma) in bf16, c1[n] = sum_k W'[n, k], bias slot = c2 = b + W beta;
+//                               rowstat = (mean, rstd) of the A rows, [M][2]; out = rstd (A W'^T - mean c1) + c2
+//   epi 5 (RES_LN): out = A W^T + bias + LayerNorm(res row) with the residual's rowstat / ln_g / ln_b (an already normalised
+//                   residual comes with identity tables: mean 0, rstd 1, gamma 1, beta 0); stats_out (or nullptr) receives (sum, sum
+//                   of squares) of every output row per 256-column tile, [M][N / 256][2], from which launch_ln_rowstat makes the
+//                   next (mean, rstd).
+struct BfEpiLn { const float* rowstat; const float* c1; const float* ln_g; const float* ln_b; float* stats_out; };
 // Scratch for the persistent bf16 GEMM's split-tail schedule (bf16.hip): 4 KB of flags + one 256 KB fp32 accumulator image per pair
 // of workgroups.  Owned by ONE engine / stream (launches that share it must be stream-ordered); epoch is bumped per launch so the
 // flags never need clearing.  nullptr: every tile is computed whole by one workgroup.
 struct GemmSplitWs { void* buf; size_t bytes; int epoch; };
 constexpr size_t MGEA_GEMM_SPLIT_WS_BYTES = 4096 + (size_t)128 * 512 * 32 * 16;   // up to 256 persistent workgroups
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* split = nullptr);
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* split = nullptr, const BfEpiLn* ln = nullptr);
+// true when launch_gemm_bf16 would run this shape on the persistent 256 x 256 kernel (the only one with epilogues 3-5)
+bool gemm_bf16_is_persistent(int M, int N, int K);
+int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st);
+int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float* beta, const float* b, void* Wf, float* c1, float* c2,
+                                int N, int K, hipStream_t st);
+int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* g, const float* be, float* out, int B, int S, int D,
+                              hipStream_t st);
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
                               float eps, void* h, int B, int S, int D, int vocab, hipStream_t st);

@@ -183,3 +183,44 @@ def test_bert_bf16_engine_vs_golden_fp32(golden, tag):
            for k, v in merged.items()}
     ref = DistilBertRef(sdr, n_heads).forward(ids, mask).numpy()
     assert np.abs(logits - ref).max() < TOL
+
+
+def _bert_logits(sd, n_heads, ids, mask, monkeypatch, fold):
+    from mgea.bert import BertEngine
+    monkeypatch.setenv("MGEA_BF16_GEMM_TILE", "4")            # every big GEMM on the persistent kernel, whatever the batch
+    if fold:
+        monkeypatch.delenv("MGEA_BERT_BF16_NOFOLD", raising=False)
+    else:
+        monkeypatch.setenv("MGEA_BERT_BF16_NOFOLD", "1")
+    eng = BertEngine(sd, n_heads=n_heads, max_tokens=ids.numel(), dtype="bf16")
+    logits, amax = eng.forward(ids, mask)
+    return logits.cpu().numpy(), amax.cpu().numpy()
+
+
+def test_bert_bf16_folded_layernorm_pipeline(monkeypatch):
+    """Big batches run without a LayerNorm kernel: the residual GEMMs write raw sums + row statistics, the next GEMM applies the
+    LayerNorm as rstd (A W'^T - mean c1) + c2 with W' = W diag(gamma), the next residual GEMM normalises its residual on the way in
+    (csrc/bert.hip).  DistilBERT-base widths, 3 layers (layer 0 starts from the materialised embedding LayerNorm, layers >= 1 use
+    the folded QKV), [8, 128] tokens with padding, every GEMM forced onto the persistent kernel: against the fp32 oracle on
+    bf16-rounded matrices (the tolerance of the other bf16 engine tests) and against the unfolded bf16 pipeline."""
+    from oracle.distilbert_ref import DistilBertRef
+    seed, vocab, max_pos, dim, n_heads, n_layers, hidden, B, S = 21, 1000, 128, 768, 12, 3, 3072, 8, 128
+    sd = synth.distilbert_state_dict(seed, vocab, max_pos, dim, n_layers, hidden)
+    ids = torch.from_numpy(synth.integers(seed, "ids", (B, S), 0, vocab))
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b in range(B):
+        mask[b, S - 7 * b:] = 0                                # ragged prompts
+    folded, amax_f = _bert_logits(sd, n_heads, ids, mask, monkeypatch, True)
+    plain, amax_p = _bert_logits(sd, n_heads, ids, mask, monkeypatch, False)
+    sdr = {k: (v.bfloat16().float() if v.ndim == 2 and "embeddings" not in k and "classifier" not in k else v) for k, v in
+           DistilBertRef(sd, n_heads).sd.items()}
+    ref = DistilBertRef(sdr, n_heads).forward(ids, mask).numpy()
+    TOL = 0.08
+    assert np.abs(plain - ref).max() < TOL
+    assert np.abs(folded - ref).max() < TOL, np.abs(folded - ref).max()
+    assert np.abs(folded - plain).max() < TOL
+    srt = np.sort(ref, 1)
+    decided = (srt[:, -1] - srt[:, -2]) > 2 * TOL
+    assert (amax_f[decided] == ref.argmax(1)[decided]).all()
+    print(f"[bf16 folded LN] max |logit - oracle|: folded {np.abs(folded - ref).max():.4f}, unfolded {np.abs(plain - ref).max():.4f}; "
+          f"folded vs unfolded {np.abs(folded - plain).max():.4f}")
