@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_FILES = ("r2_pmc_fetch_size_full.json", "r1_v6_pmc_fetch_size_full.json")   # newest committed FETCH_SIZE pass first
+PMC_FILES = ("r3_pmc_fetch_size_attn.json", "r2_pmc_fetch_size_full.json", "r1_v6_pmc_fetch_size_full.json")   # newest committed FETCH_SIZE pass first
 
 DEC = dict(vocab=8324, seq_len=1024, d_model=512, n_layer=6, d_ff=2048)   # train/train_large2.py:10-12,23-28
 N_HEAD = 8                                                                 # api_cache.py:112
@@ -93,7 +93,7 @@ def cpu_baseline_decoder(sd, prompts, budget_s):
                        f"steps (ctx <= {idx.shape[1] + n}), {dt:.1f} s")
 
 
-def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None):
+def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None, ref_logits=None, keep_logits=False):
     from mgea import synth
     from mgea.bert import BertEngine
     B, S = 256, 128
@@ -103,6 +103,17 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None):
     eng = BertEngine(sd, n_heads=12, adapter=ad, max_tokens=B * S, device=device, dtype=dtype)
     ids, mask = synth.bert_inputs(2, B, S, BERT["vocab"])
     ids, mask = torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)
+    check = None
+    if ref_logits is not None:
+        # the timed configuration is checked before it is timed: all 256 rows against the f32 parity engine's logits on the same ids
+        lg, am = eng.forward(ids, mask)
+        d = (lg - ref_logits).abs().max(1).values
+        srt = ref_logits.sort(1).values
+        decided = (srt[:, -1] - srt[:, -2]) > 0.16
+        agree = bool((am[decided].long() == ref_logits.argmax(1)[decided]).all())
+        check = dict(vs="f32 engine, same ids, 256 rows", max_abs_logit_diff=float(d.max()), mean_row_max=float(d.mean()), tolerance=0.08,
+                     rows_with_top2_gap_over_0p16=int(decided.sum()), labels_equal_on_those=agree, kernels=eng.stats())
+        assert float(d.max()) < 0.08 and agree, f"bf16 DistilBERT logits off the f32 engine: {check}"
     for _ in range(max(1, warmup)):
         eng.forward(ids, mask)
     torch.cuda.synchronize()
@@ -127,8 +138,45 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None):
         dtc = time.perf_counter() - t0
         out["cpu_baseline"] = dict(value=n / dtc, unit="prompts/s", cores=torch.get_num_threads(), kind="port",
                                    sample=f"oracle/distilbert_ref.py, first {n} rows of the batch, one forward, {dtc:.1f} s")
+    if check is not None:
+        out["parity_check"] = check
+    if keep_logits:
+        out["_logits"] = eng.forward(ids, mask)[0].clone()
     eng.close()
     return out
+
+
+def b1_extra(arena, device, TL=1024, Tp=5):
+    """The reference's actual serving case (api_cache.py:204: B = 1, top_k = 50, a fresh seed per request) and the only
+    figure the reference publishes for this path (0.29 ms per token with its KV cache on an RTX A4000, 6L / 512d,
+    seq 512): one warm-up request, then two timed 1019-step requests with new seeds through the cached step graph."""
+    from mgea.decoder import DecoderEngine
+    eng = DecoderEngine(None, n_head=N_HEAD, max_batch=1, max_ctx=TL, device=device, geometry=DEC, arena=arena)
+    p = [[1, 2, 3, 4, 5][:Tp]]
+    n = TL - Tp
+    eng.generate(p, n, temperature=1.0, top_k=50, seed=1)
+    torch.cuda.synchronize()
+    i0 = eng.stats()["graph_instantiates"]
+    ts = []
+    for seed in (101, 102):
+        t0 = time.perf_counter()
+        out = eng.generate(p, n, temperature=1.0, top_k=50, seed=seed).cpu()       # incl. reset, prefill and the D2H copy of the ids
+        ts.append(time.perf_counter() - t0)
+    assert int(out.min()) >= 0 and int(out.max()) < DEC["vocab"]
+    st = eng.stats()                                   # before the greedy leg below, which captures its own (greedy) step graph
+    eng.generate(p, n, temperature=1.0, top_k=1).cpu()
+    t0 = time.perf_counter()
+    eng.generate(p, n, temperature=1.0, top_k=1).cpu()
+    tg = time.perf_counter() - t0
+    eng.close()
+    dt = min(ts)
+    return {"metric": "decoder_latency_per_token", "value": dt / n * 1e3, "unit": "ms/token", "higher_is_better": False, "batch": 1,
+            "tokens_per_sec": n / dt, "us_per_step": dt / n * 1e6, "ms_per_request": [round(t * 1e3, 2) for t in ts],
+            "us_per_step_greedy": tg / n * 1e6, "sampler": {"temperature": 1.0, "top_k": 50},
+            "graph_instantiations_during_timed_requests": st["graph_instantiates"] - i0, "graph_nodes": st["graph_nodes"],
+            "published_reference": {"value": 0.29, "unit": "ms/token", "hardware": "RTX A4000", "source": "BASELINE.md (paper, KV cache, B=1)"},
+            "vs_published": 0.29 / (dt / n * 1e3),
+            "workload": f"Decoder-S B=1 prompt {Tp} total_len {TL}, top_k=50 multinomial, fresh seed per request (api_cache.py:204), random weights"}
 
 
 def large_batch_extra(arena, device, B, Tp, TL):
@@ -240,11 +288,13 @@ def dry_run(args, backend):
     ok = bool(np.array_equal(arena.numpy(), synth.uniform(9, "arena", (n,))))
     if world > 1:
         dist.barrier()
+    per_rank = mdist.all_gather_floats(1000.0 + rank, "cpu")
     dt = mdist.all_reduce_max(1e-3 * (rank + 1), "cpu")
-    assert ok and abs(dt - 1e-3 * world) < 1e-12
+    assert ok and abs(dt - 1e-3 * world) < 1e-12 and per_rank == [1000.0 + r for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "midi_tokens_per_sec", "value": 0.0, "unit": "tokens/s", "n_gpus": world, "steps": 0, "warmup": 0,
                           "dry_run": True, "backend": dist.get_backend() if world > 1 else None, "scaling": "weak",
+                          "per_rank_tokens_per_sec": per_rank,
                           "config": {"workload": "launch-path rehearsal: no GPU work", "parallelism": parallelism_label(world, backend, n * 4, 0.0)}}))
     if world > 1:
         dist.destroy_process_group()
@@ -263,8 +313,8 @@ def main():
     from mgea import launch
     if args.gpus > 1 and not launch.launched_by_a_launcher():
         # no launcher: start the N ranks ourselves, BEFORE anything initialises the GPU in this process
-        # (torch.cuda.device_count() does not, on this image)
-        ndev = torch.cuda.device_count()
+        # (devices counted from sysfs: no HIP or torch device query in the parent)
+        ndev = launch.count_gpus()
         raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, backend, None if args.dry_run else ndev))
     if args.dry_run:
         return dry_run(args, backend)
@@ -321,6 +371,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = mdist.all_gather_floats(args.steps * B * n_steps / dt, device)   # each rank's own tokens/s: a straggler shows in the line
     dt = mdist.all_reduce_max(dt, device)
     tokens = world * args.steps * B * n_steps
     value = tokens / dt
@@ -354,8 +405,8 @@ def main():
                 for k, v in rec.items():
                     if "attn_paged_kernel" in k and isinstance(v, dict):
                         traffic = v["mean"] * 1024 * 2
-                        traffic_source = (f"committed PMC constant profiles/{name} @ {rec.get('_commit', 'round-1 commit 81e2dc6')}: rocprofv3 --pmc "
-                                          f"FETCH_SIZE over the same generation run eagerly (MGEA_DECODER_NOGRAPH=1), mean of {v.get('n', 6114)} launches")
+                        traffic_source = (f"committed PMC constant profiles/{name} @ {rec.get('_commit', 'unknown')}: {rec.get('_command', 'rocprofv3 --pmc FETCH_SIZE')}, "
+                                          f"mean of {v.get('n', v.get('dispatches', 'unknown'))} launches")
                 break
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_source=traffic_source, kernel="attn_paged_kernel<64>", launches=a["launches"],
@@ -379,6 +430,7 @@ def main():
                        "global_batch": B * world, "seq_len": TL,
                        "parallelism": parallelism_label(world, backend, total * 4, t_bcast)},
             "tokens_per_sec_per_gpu": value / world,
+            "per_rank_tokens_per_sec": [round(v, 1) for v in per_rank],
             "whole_step_hbm_frac": step_bytes * args.steps / (dt) / 1e9 / HBM_PEAK_GBS,
             "graph": eng.stats(),
             "roofline": roof,
@@ -391,8 +443,8 @@ def main():
             eng = None
             extra["decoder_prefill"] = prefill_extra(arena, device)
         if not args.no_bert and not args.no_extra and world == 1:
-            extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu)
-            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16")
+            extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu, keep_logits=True)
+            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16", ref_logits=extra["distilbert"].pop("_logits"))
         if world == 1 and not args.no_extra:
             # BASELINE configs[4] as written: fp16 storage, top-p 0.9, 2048 tokens, captured step graph (one GPU's share)
             top_p = dict(temperature=1.0, top_k=None, top_p=0.9, seed=1)
@@ -403,6 +455,7 @@ def main():
                                                        note="the headline generation in fp16 storage (perf mode, not the parity mode)")
             # informational: the headline generation at 4x the batch per GPU (still the fused 32-launch step)
             extra["decoder_batch256"] = large_batch_extra(arena, device, 256, Tp, TL)
+            extra["decoder_b1"] = b1_extra(arena, device)
         if extra:
             line["extra"] = extra
     if eng is not None:

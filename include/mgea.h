@@ -50,6 +50,11 @@ extern "C" {
 
 const char* mgea_last_error(void);
 int mgea_version(void);
+/* A/B and test switches (tools/README.md lists them).  The table is filled once, when the library is loaded, from the
+ * MGEA_<NAME> environment variables; these two calls read / change an entry at run time.  Nothing on a launch path reads the
+ * environment, and no switch is needed in production. */
+int mgea_tune_set(const char* name, int32_t value);
+int mgea_tune_get(const char* name, int32_t* value_out);
 /* number of visible HIP devices, or a negative error */
 int mgea_device_count(void);
 
@@ -178,6 +183,11 @@ int mgea_bert_destroy(mgea_bert* h);
  * argmax_out_dev [B] int32 (either may be NULL). */
 int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
                       int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
+/* What the handle ran (so that a test can assert WHICH kernels produced the numbers it checks): out[0] forwards so far; of the
+ * last forward: [1] 1 = folded-LayerNorm bf16 pipeline, [2] / [3] / [4] bf16 GEMM launches on the persistent 256 x 256 kernel /
+ * a ring kernel / the 128 x 128 kernel, [5] persistent launches that cut their left-over tiles into 128-row halves,
+ * [6] LayerNorm kernel launches, [8 + e] bf16 GEMM launches with epilogue e (0..5); others 0. */
+int mgea_bert_stats(mgea_bert* h, int64_t* out /* [16] */);
 
 /* W[out,in] += scale * B[out,r] @ A[r,in] in place (peft LoRA fold, W' = W + (alpha/r) B A;
  * Scripts/finetuneDistillBert.ipynb:787-795). */
@@ -208,16 +218,25 @@ int mgea_op_attention_f32(const float* qkv_dev, const int32_t* lens_dev, const i
 int mgea_op_f32_to_bf16(const float* src_dev, void* dst_dev, int64_t n, void* stream);
 int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
                       void* out_dev, int32_t M, int32_t N, int32_t K, int32_t epi, void* stream);
-/* The same GEMM with the engine's scratch for the "split tail" schedule of the persistent 256 x 256 kernel: when the output has
- * more tiles than the GPU has CUs, the tiles left after the full rounds number at most half the workgroups and K >= 2048
- * (DistilBERT's FFN down-projection: 384 tiles on 256 CUs, K = 3072), each left-over tile is shared by two workgroups, one per
- * half of K, which meet through scratch_dev (mgea_op_gemm_bf16_scratch_bytes() bytes, first 4 KB zeroed once; launches sharing
- * one scratch must be stream-ordered).  *epoch_io is a launch counter owned by the caller (start at 0); results are
- * deterministic.  Other shapes run exactly as mgea_op_gemm_bf16. */
-int64_t mgea_op_gemm_bf16_scratch_bytes(void);
-int mgea_op_gemm_bf16_split(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
-                            void* out_dev, int32_t M, int32_t N, int32_t K, int32_t epi, void* scratch_dev,
-                            int64_t scratch_bytes, int32_t* epoch_io, void* stream);
+/* The same GEMM with the LayerNorm-folding epilogues of the big-batch DistilBERT pipeline (persistent 256 x 256 kernel only:
+ * M >= 512, N % 256 == 0; csrc/common.h BfEpiLn), so that the kernel combination the engine picks at B = 256 / S = 128 can be
+ * checked in isolation:
+ *   epi 3 / 4: out = rstd_row (a w'^T - mean_row c1) + c2 [+ GELU]: a = RAW rows, w' = bf16(W diag(gamma)), bias_dev = c2,
+ *              rowstat_dev [M][2] = (mean, rstd) of the a rows (mgea_op_fold_ln_bf16 makes w' / c1 / c2);
+ *   epi 5:     out = a w^T + bias + LayerNorm(res row; rowstat_dev, ln_g_dev, ln_b_dev); stats_out_dev [M][N / 256][2] (or NULL)
+ *              receives per 256-column tile (sum, M2 about the tile mean) of every output row, which mgea_op_ln_rowstat turns
+ *              into the next (mean, rstd);
+ *   epi 0..2 as mgea_op_gemm_bf16 (the LayerNorm pointers are ignored).
+ * info_out [2] (host, or NULL): [0] the kernel that ran (0 128 x 128 register-staged, 1 ring, 2 persistent), [1] 1 when the
+ * persistent kernel cut its left-over tiles into two independent 128-row halves (tiles % CUs <= CUs / 2). */
+int mgea_op_gemm_bf16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev, void* out_dev,
+                         int32_t M, int32_t N, int32_t K, int32_t epi, const float* rowstat_dev, const float* c1_dev,
+                         const float* ln_g_dev, const float* ln_b_dev, float* stats_out_dev, int32_t* info_out, void* stream);
+int mgea_op_ln_rowstat(const float* part_dev, float* rowstat_dev, int32_t M, int32_t n_part, int32_t C, float eps,
+                       void* stream);
+/* wf_out_dev [N,K] bf16 = bf16(W diag(gamma)); c1[n] = sum_k of the ROUNDED wf[n,k]; c2[n] = bias[n] + sum_k W[n,k] beta[k]. */
+int mgea_op_fold_ln_bf16(const float* w_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, int32_t N,
+                         int32_t K, void* wf_out_dev, float* c1_out_dev, float* c2_out_dev, void* stream);
 int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,
                            int32_t n_head, int32_t head_dim, void* stream);
 int mgea_op_layernorm_bf16(const void* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int32_t M,

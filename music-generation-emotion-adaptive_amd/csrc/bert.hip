@@ -64,7 +64,10 @@ struct mgea_bert {
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *slabs = nullptr, *pooled = nullptr,
           *pooled2 = nullptr;
     void *wb = nullptr, *hb = nullptr, *qkvb = nullptr, *ctxb = nullptr, *ffnb = nullptr, *tmpb = nullptr;  // bf16 mode
-    GemmSplitWs split{nullptr, 0, 0};                        // bf16 mode: scratch of the persistent GEMM's split-tail schedule
+    // what the last forward ran (mgea_bert_stats): forwards so far; folded-LayerNorm pipeline or not; bf16 GEMM launches by kernel
+    // (persistent / ring / small), persistent launches that cut their tail tiles in halves, by epilogue (0..5); LayerNorm kernels
+    int64_t n_forwards = 0, last_fold = 0, last_persistent = 0, last_ring = 0, last_small = 0, last_half_tiles = 0, last_ln_kernels = 0;
+    int64_t last_epi[6] = {0, 0, 0, 0, 0, 0};
     // bf16 mode, folded-LayerNorm pipeline (big batches: every GEMM on the persistent kernel): W diag(gamma) copies, c1 / c2 vectors,
     // per-tile row sums and the two (mean, rstd) tables
     void* wfold = nullptr;
@@ -99,7 +102,7 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_destroy(mgea_bert* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->split.buf, h->wfold, h->fvec, h->stats_part, h->rowstat_sa, h->rowstat_out, h->ident};
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->wfold, h->fvec, h->stats_part, h->rowstat_sa, h->rowstat_out, h->ident};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;
@@ -136,10 +139,7 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
              hipMalloc(&h->qkvb, M * 3 * D * 2) == hipSuccess && hipMalloc(&h->ctxb, M * D * 2) == hipSuccess &&
              hipMalloc(&h->ffnb, M * Hd * 2) == hipSuccess && hipMalloc(&h->tmpb, M * D * 2) == hipSuccess &&
              hipMalloc((void**)&h->slabs, h->slab_cap * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
-             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess &&
-             hipMalloc(&h->split.buf, MGEA_GEMM_SPLIT_WS_BYTES) == hipSuccess &&
-             hipMemset(h->split.buf, 0, 4096) == hipSuccess;                       // the flags; epochs start at 1
-        if (ok) h->split.bytes = MGEA_GEMM_SPLIT_WS_BYTES;
+             hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
         if (ok) ok = launch_f32_to_bf16(arena_dev, h->wb, total, nullptr) == MGEA_OK && hipDeviceSynchronize() == hipSuccess;
         if (ok) {   // folded-LayerNorm pipeline (see mgea_bert_forward): FC1 of every layer, QKV of layers >= 1
             const int64_t L = cfg->n_layers;
@@ -200,6 +200,17 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     if (c.dtype == MGEA_DTYPE_BF16) {
         // perf mode: bf16 MFMA GEMMs with fused bias / GELU / residual epilogues, bf16 flash attention
         auto wb = [&](int l, int j) { return (const void*)h->wbf(h->off[B_HEAD0 + l * BL_COUNT + j]); };
+        h->last_fold = h->last_persistent = h->last_ring = h->last_small = h->last_half_tiles = h->last_ln_kernels = 0;
+        for (int64_t& e : h->last_epi) e = 0;
+        auto bgemm = [&](const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C, int ldc, int m, int n,
+                         int k, int epi, const BfEpiLn* ln = nullptr) -> int {
+            GemmBf16Info gi{0, 0};
+            MGEA_TRY(launch_gemm_bf16(A, lda, W, ldw, bias, res, C, ldc, m, n, k, epi, st, &gi, ln));
+            (gi.kernel == 2 ? h->last_persistent : gi.kernel == 1 ? h->last_ring : h->last_small) += 1;
+            h->last_half_tiles += gi.half_tiles;
+            h->last_epi[epi] += 1;
+            return MGEA_OK;
+        };
         MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
                                            S, D, c.vocab, st));
         // Folded-LayerNorm pipeline: when every GEMM of a layer runs on the persistent 256 x 256 kernel (big batches), no LayerNorm
@@ -208,43 +219,44 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         // c1) + c2 with W' = W diag(gamma) (epilogues 3 / 4), the next residual GEMM by normalising the residual row on the way in
         // (epilogue 5), the classifier head on its B CLS rows.  Saves a read + write of [M, D] per LayerNorm (12 x 20 us at the bench
         // shape).  hb and tmpb alternate as the raw buffers; layer 0 starts from the materialised embedding LayerNorm.
-        const bool nofold = getenv("MGEA_BERT_BF16_NOFOLD") != nullptr;   // A/B and tests
-        const bool fold = !nofold && D % 256 == 0 && Hd % 256 == 0 && gemm_bf16_is_persistent(M, 3 * D, D) && gemm_bf16_is_persistent(M, D, D) &&
+        const bool fold = !tune(TUNE_BERT_BF16_NOFOLD) && D % 256 == 0 && Hd % 256 == 0 && gemm_bf16_is_persistent(M, 3 * D, D) && gemm_bf16_is_persistent(M, D, D) &&
                           gemm_bf16_is_persistent(M, Hd, D) && gemm_bf16_is_persistent(M, D, Hd);
+        h->last_fold = fold ? 1 : 0;
         if (fold) {
             const int npart = D / 256;
             const float *id_g = h->ident + (int64_t)c.max_tokens * 2, *id_b = id_g + D;
             for (int l = 0; l < c.n_layers; ++l) {
                 const bool first = l == 0;
                 if (first) {
-                    MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st, &h->split));
+                    MGEA_TRY(bgemm(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0));
                 } else {
                     BfEpiLn q{h->rowstat_out, h->qkvc(l, 0), nullptr, nullptr, nullptr};
-                    MGEA_TRY(launch_gemm_bf16(h->hb, D, h->qkvf(l), D, h->qkvc(l, 1), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 3, st, &h->split, &q));
+                    MGEA_TRY(bgemm(h->hb, D, h->qkvf(l), D, h->qkvc(l, 1), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 3, &q));
                 }
                 MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
                 // out-proj + LayerNorm_out(l-1)(raw hb) as the residual (layer 0: hb is already normalised) -> raw tmpb + row sums
                 BfEpiLn o{first ? h->ident : h->rowstat_out, nullptr, first ? id_g : h->lw(l - 1, BL_OLNW), first ? id_b : h->lw(l - 1, BL_OLNB),
                           h->stats_part};
-                MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 5, st, &h->split, &o));
+                MGEA_TRY(bgemm(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 5, &o));
                 MGEA_TRY(launch_ln_rowstat(h->stats_part, h->rowstat_sa, M, npart, D, c.ln_eps, st));
                 BfEpiLn f1{h->rowstat_sa, h->fc1c(l, 0), nullptr, nullptr, nullptr};
-                MGEA_TRY(launch_gemm_bf16(h->tmpb, D, h->fc1f(l), D, h->fc1c(l, 1), nullptr, h->ffnb, Hd, M, Hd, D, 4, st, &h->split, &f1));
+                MGEA_TRY(bgemm(h->tmpb, D, h->fc1f(l), D, h->fc1c(l, 1), nullptr, h->ffnb, Hd, M, Hd, D, 4, &f1));
                 // FC2 + LayerNorm_sa(l)(raw tmpb) as the residual -> raw hb + row sums
                 BfEpiLn f2{h->rowstat_sa, nullptr, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->stats_part};
-                MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->tmpb, h->hb, D, M, D, Hd, 5, st, &h->split, &f2));
+                MGEA_TRY(bgemm(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->tmpb, h->hb, D, M, D, Hd, 5, &f2));
                 MGEA_TRY(launch_ln_rowstat(h->stats_part, h->rowstat_out, M, npart, D, c.ln_eps, st));
             }
             MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(c.n_layers - 1, BL_OLNW), h->lw(c.n_layers - 1, BL_OLNB), h->pooled, B, S,
                                                D, st));
         } else {
         for (int l = 0; l < c.n_layers; ++l) {
-            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0, st, &h->split));
+            MGEA_TRY(bgemm(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0));
             MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
-            MGEA_TRY(launch_gemm_bf16(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2, st, &h->split));
+            MGEA_TRY(bgemm(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->hb, M, D, c.ln_eps, st));
-            MGEA_TRY(launch_gemm_bf16(h->hb, D, wb(l, BL_L1W), D, h->lw(l, BL_L1B), nullptr, h->ffnb, Hd, M, Hd, D, 1, st, &h->split));
-            MGEA_TRY(launch_gemm_bf16(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2, st, &h->split));
+            h->last_ln_kernels += 2;
+            MGEA_TRY(bgemm(h->hb, D, wb(l, BL_L1W), D, h->lw(l, BL_L1B), nullptr, h->ffnb, Hd, M, Hd, D, 1));
+            MGEA_TRY(bgemm(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
         }
         MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
@@ -284,6 +296,17 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_TRY(gemm(h->pooled2, D, h->hw(2), B, NL, D, &Sk));
     MGEA_TRY(launch_logits_argmax(h->slabs, Sk, slab_floats(B, NL), (int)slab_ld(NL), h->hw(3), logits_out_dev, B, NL,
                                   argmax_out_dev, st));
+    h->n_forwards += 1;
+    return MGEA_OK;
+}
+
+int mgea_bert_stats(mgea_bert* h, int64_t* out) {
+    MGEA_REQUIRE(h && out, MGEA_EINVAL, "bert_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    out[0] = h->n_forwards; out[1] = h->last_fold; out[2] = h->last_persistent; out[3] = h->last_ring; out[4] = h->last_small;
+    out[5] = h->last_half_tiles; out[6] = h->last_ln_kernels;
+    for (int e = 0; e < 6; ++e) out[8 + e] = h->last_epi[e];
     return MGEA_OK;
 }
 

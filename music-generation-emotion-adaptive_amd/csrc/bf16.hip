@@ -21,6 +21,8 @@ namespace mgea {
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
@@ -196,9 +198,6 @@ __global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t*
     constexpr int WPW = (BN / 8) / (4 * WMW);           // W pieces (8 rows x 128 B) per wave per tile
     constexpr int SA = BM * 8, STAGE = (BM + BN) * 8;   // in 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE]
-    const int dbg = tiles_n >> 16;   // ablation bits from MGEA_BF16_GEMM_DBG (0 in production)
-    tiles_n &= 0xffff;
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
@@ -262,10 +261,9 @@ __global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t*
     for (int t = 0; t < KT; ++t) {
         const float4* sb = lds + cur * STAGE;
         const bool more = t + NS - 1 < KT;
-        if (more && !(dbg & 1)) issue(nxt, t + NS - 1);
+        if (more) issue(nxt, t + NS - 1);
         cur = cur + 1 == NS ? 0 : cur + 1;
         nxt = nxt + 1 == NS ? 0 : nxt + 1;
-        if (dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); continue; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[NT];
@@ -385,7 +383,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                           bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
-                                                          float4* __restrict__ split_ws, int* __restrict__ split_flags, int epoch, int split_min_kt, BfEpiLn ln) {
+                                                          int tail_mode, BfEpiLn ln) {
     constexpr int BM = 256, BN = 256;
     constexpr bool LNF = EPI == BEPI_LNFOLD || EPI == BEPI_LNFOLD_GELU;
     constexpr bool RESV = EPI == BEPI_BIAS_RES || EPI == BEPI_RES_LN;
@@ -406,48 +404,55 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
     const int slot = (int)blockIdx.x >> 3;
     const int run0 = ((int)blockIdx.x & 7) * ((n_tiles + 7) >> 3);
     const int per_x = (run0 + ((n_tiles + 7) >> 3) < n_tiles ? ((n_tiles + 7) >> 3) : n_tiles - run0);   // tiles in this XCD's run (<= 0: none)
-    // SPLIT TAIL: 384 tiles on 256 workgroups are one full round and a half-empty one.  When the tiles left over after the full
-    // rounds number at most half the XCD's workgroups, each of them is shared by two workgroups, one per half of K, which swap
-    // half of their fp32 partial sums through the engine's scratch and finalise half of the tile each (see the exchange below).
-    // Neither waits before it has published its own half, so the pair cannot deadlock; both are co-resident (one workgroup per
-    // CU).  The exchange costs ~15-20 us (256 KB per workgroup through the coherence point + the skew of the pair), half a tile
-    // saves 0.75 us per K-tile: worth it from K = 2048 on (measured, tools/gemm_bf16_bench.py: K = 3072 167 -> 148 us, K = 768
-    // 60 -> 63 and 124 -> 135 us), so K = 768 keeps its whole tiles.
+    // HALF-TILE TAIL: 384 tiles on 256 workgroups are one full round and a half-empty one.  When the tiles left over after the full
+    // rounds number at most half the XCD's workgroups, each of them is cut into two 128-row halves computed by two workgroups
+    // INDEPENDENTLY (no exchange, no scratch, no co-residency assumption -- round 2 cut K instead and swapped fp32 partial sums
+    // through a coherent scratch, which two such launches sharing the GPU could deadlock on): a half unit keeps the 256-wide W tile
+    // and the whole K loop, its 8 waves own 64 x 64 of C each, in a K loop of its own (3 LDS stages of 48 KB, 2 phases per K-tile:
+    // "HALF UNITS" below).  Every output element sees the same MFMA sequence over K as in a whole tile: the two schedules are
+    // bitwise identical.  tail_mode 2 additionally lets the odd slots run their half unit FIRST, so that the two halves of the chip
+    // reach their store bursts half a tile apart.
     const int full_rounds = per_x > 0 ? per_x / wg_x : 0, rem = per_x > 0 ? per_x - full_rounds * wg_x : 0;
-    const bool split = split_ws && rem > 0 && 2 * rem <= wg_x && KT >= split_min_kt;
-    int u_tile = 0, u_kt0 = 0, u_nkt = 0, u_mode = 0;       // mode 0: whole tile, 1 / 2: first / second half of K of a shared tile
+    const bool split = tail_mode != 0 && rem > 0 && 2 * rem <= wg_x;
+    const bool half_first = split && tail_mode == 2 && (slot & 1) && slot < 2 * rem;
+    int u_tile = 0, u_mode = 0;                              // mode 0: whole tile, 1 / 2: rows 0..127 / 128..255 of a shared tile
     auto get_unit = [&](int ui) -> bool {                   // the ui-th unit of this workgroup
-        if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_kt0 = 0; u_nkt = KT; u_mode = 0; return true; }
+        if (half_first) {                                    // the tail unit comes first, the whole tiles after it
+            if (ui == 0) { u_tile = run0 + full_rounds * wg_x + (slot >> 1); u_mode = 1 + (slot & 1); return true; }
+            ui -= 1;
+            if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_mode = 0; return true; }
+            return false;
+        }
+        if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_mode = 0; return true; }
         if (ui > full_rounds) return false;
         if (split) {
             if (slot >= 2 * rem) return false;
             u_tile = run0 + full_rounds * wg_x + (slot >> 1);
-            u_kt0 = (slot & 1) ? KT / 2 : 0; u_nkt = (slot & 1) ? KT - KT / 2 : KT / 2; u_mode = 1 + (slot & 1);
+            u_mode = 1 + (slot & 1);
             return true;
         }
         if (slot >= rem) return false;
-        u_tile = run0 + full_rounds * wg_x + slot; u_kt0 = 0; u_nkt = KT; u_mode = 0;
+        u_tile = run0 + full_rounds * wg_x + slot; u_mode = 0;
         return true;
     };
-    const int split_idx = ((int)blockIdx.x & 7) * (wg_x >> 1) + (slot >> 1);   // this workgroup's pair in the scratch
 
     // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
     // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
     const bf16_t* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
     int m0 = 0, n0 = 0;
-    auto set_tile = [&](int t, int kt0) {
-        m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
+    auto set_tile = [&](int t, int md) {                    // md != 0: the 128 rows of that half sit in rows 0..127 of the A stage
+        m0 = (t / tiles_n) * BM + (md == 2 ? 128 : 0); n0 = (t % tiles_n) * BN;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
                 ra = ra < M ? ra : M - 1;
-                src[hf][i] = A + (int64_t)ra * lda + lch * 8 + kt0 * 64;
+                src[hf][i] = A + (int64_t)ra * lda + lch * 8;
                 int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
                 rw = rw < N ? rw : N - 1;
-                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8 + kt0 * 64;
+                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
             }
     };
     auto issue_half = [&](int hid, int kt) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
@@ -459,32 +464,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             glds16_hidden(src[hid][i] + kt * 64, dst);
         }
     };
-    // tile 0 whole, then the first two half-tiles of tile 1 (the steady state issues W0 / A0 of K-tile u+2 in phases 4u+2 / 4u+3
-    // and W1 / A1 of K-tile u+1 in phases 4u / 4u+1)
-    auto issue_prologue = [&](int nkt) {
-        issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
-        if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); }
+    // HALF UNITS (128 x 256 of C, mode 1 / 2) have their own K loop: a K-tile is A 128 rows (16 KB) + W 256 rows (32 KB) = 48 KB, so
+    // THREE stages fit where the whole tiles have two (stage 2 = bytes 96 K .. 144 K overlaps the epilogue's C stage, which is only
+    // live between two K loops), and a K-tile is consumed in TWO phases of 16 MFMAs per wave (each wave owns 64 x 64 of C: quadrants
+    // (0, 0) and (0, 1) of the whole-tile wave tile) -- half the barriers of the 4-phase loop, which with two of its phases empty
+    // took 0.82 of a whole tile's time for half the work.  Schedule (phase q = 2u + p of K-tile u, stage u % 3; early / late wave
+    // groups as above: L(q) / C(q) = intervals 2q / 2q+1 resp. 2q+1 / 2q+2):
+    //   reads : p0 reads W(j=0) + A, p1 reads W(j=1); every ds_read complete (lgkmcnt(0)) before the barrier that ends its L-segment,
+    //           so stage u % 3 is last read in interval 2(2u+1)+1 = 4u+3.
+    //   WAR   : stage (u+3) % 3 = u % 3 is refilled with K-tile u+3 in phases 2(u+1) (W0) and 2(u+1)+1 (A0, W1), first interval
+    //           2(2u+2) = 4u+4 > 4u+3.
+    //   RAW   : K-tile u+1 is first read in interval 2*2(u+1) = 4u+4; all its DMAs were issued in phases 2u-2, 2u-1 (or the
+    //           prologue); every wave waits for ITS pieces at the end of interval 4u+3 (early: end of C(2u+1), late: end of
+    //           L(2u+1)) with vmcnt(6) -- only the 6 DMAs of K-tile u+2, issued in phases 2u and 2u+1, may still be in flight --
+    //           and the barrier that ends that interval publishes them.
+    constexpr int HSA = 128 * 8, HSTAGE = (128 + 256) * 8;   // half units: 16-byte chunks of the A part / of a stage
+    auto issue_h = [&](int hid, int kt, int st3) {          // hid 0: A rows 0..127, 2 / 3: W rows 0..127 / 128..255
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
+            const unsigned dst = lds_base + (unsigned)(st3 * HSTAGE + (hid >= 2 ? HSA : 0) + row0 * 8) * 16u;
+            glds16_hidden(src[hid][i] + kt * 64, dst);
+        }
+    };
+    // whole tiles: tile 0 whole, then the first two half-tiles of tile 1 (the steady state issues W0 / A0 of K-tile u+2 in phases
+    // 4u+2 / 4u+3 and W1 / A1 of K-tile u+1 in phases 4u / 4u+1); half units: K-tiles 0 and 1 whole (6 + 6 DMAs per wave)
+    auto issue_prologue = [&](int nkt, int md) {
+        if (md == 0) {
+            issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
+            if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); }
+        } else {
+            issue_h(2, 0, 0); issue_h(0, 0, 0); issue_h(3, 0, 0);
+            if (nkt > 1) { issue_h(2, 1, 1); issue_h(0, 1, 1); issue_h(3, 1, 1); }
+        }
     };
 
     int ui = 0;
     bool have = get_unit(0);
-    if (have) { set_tile(u_tile, u_kt0); issue_prologue(u_nkt); }
+    if (have) { set_tile(u_tile, u_mode); issue_prologue(KT, u_mode); }
     while (have) {
-        const int cm0 = m0, cn0 = n0;                       // this tile's origin (set_tile moves on to the next one below)
-        const int nkt = u_nkt, mode = u_mode;               // this unit's K-tiles: [u_kt0, u_kt0 + nkt), folded into src[] by set_tile
+        const int cm0 = m0, cn0 = n0;                       // this unit's origin (set_tile moves on to the next one below)
+        const int nkt = KT, mode = u_mode;
+        const bool halfu = mode != 0;                       // workgroup-uniform
+        const int wrows = halfu ? 64 : 128;                 // rows of the unit per wave row wm
         f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // K-tile 0 has landed when at most the 4 DMAs of K-tile 1's first halves are still in flight.  (After the first tile the
-        // previous epilogue's stores are younger than these DMAs and count too: the wait is then stronger, never weaker.)
-        if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // K-tile 0 has landed when at most the DMAs of K-tile 1 issued by the prologue (4 for a whole tile, 6 for a half unit) are
+        // still in flight.  (After the first unit the previous epilogue's stores are younger than these DMAs and count too: the
+        // wait is then stronger, never weaker.)
+        if (nkt > 1) {
+            if (halfu) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
 
         bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
+        if (!halfu) {
         for (int u = 0; u < nkt; ++u) {
             const float4* sb = lds + (u & 1) * STAGE;
             const float4* sa = sb + (wm * 128) * 8;
@@ -544,6 +585,65 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 __builtin_amdgcn_s_barrier();
             }
         }
+        } else {
+        int st3 = 0, st3n = 2;                                // ring slots of K-tile u and of K-tile u + 2
+        for (int u = 0; u < nkt; ++u) {
+            const float4* sb = lds + st3 * HSTAGE;
+            const float4* sa = sb + (wm * 64) * 8;
+            const float4* sw = sb + HSA + (wn * 64) * 8;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // ---------------- L-segment
+#pragma unroll
+                for (int n = 0; n < 2; ++n)      // W fragments of the 32-column half j = p
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                        if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                    }
+                if (p == 0) {                    // A fragments: the wave's 64 rows
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const float4 v = sa[(m * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                            af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (p == 0 && u + 2 < nkt) issue_h(2, u + 2, st3n);
+                if (p == 1 && u + 2 < nkt) { issue_h(0, u + 2, st3n); issue_h(3, u + 2, st3n); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (p == 1 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(2u+1) ...
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- C-segment: quadrant (0, j = p)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const bf16x8 wv = p ? bf1[n][ks] : bf0[n][ks];
+                            acc[p * 2 + n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[p * 2 + n][m], 0, 0, 0);
+                        }
+                __builtin_amdgcn_s_setprio(0);
+                if (p == 1 && wm == 0) {     // ... the early group at the end of its C(2u+1): the same interval
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            st3 = st3 == 2 ? 0 : st3 + 1;
+            st3n = st3n == 2 ? 0 : st3n + 1;
+        }
+        }
         if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
 
         // Both operand stages are free now (every read of the last K-tiles completed before the barriers above): put the NEXT
@@ -555,76 +655,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         have = get_unit(++ui);
-        if (have) { set_tile(u_tile, u_kt0); issue_prologue(u_nkt); }
+        if (have) { set_tile(u_tile, u_mode); issue_prologue(KT, u_mode); }
 
-        int mshift = 0, kpass = 4;                             // epilogue: m-tile of acc[.][j] is j + mshift; passes of 2 m-tiles
-        if (mode != 0) {
-            // Split units come last (have == false): no DMA is in flight.  SYMMETRIC exchange: both workgroups of the pair hold partial
-            // sums of the whole tile (their half of K); workgroup h finalises the m-tiles 4h .. 4h+3 of every wave and ships the
-            // other four to its partner.  After the swap below the code is the same for both (one path: a producer path and a consumer
-            // path side by side, each with 128 live accumulators, pushed spills into the MFMA loop of a kernel without a register to
-            // spare): acc[.][0..3] = mine, acc[.][4..7] = the partner's.
-            // Coherence without fences: an agent-scope release / acquire pair writes back and invalidates a whole L2 on this 8-XCD part
-            // (+100 us per GEMM when it was tried); the partials are written and read with relaxed AGENT-scope atomics instead (sc1:
-            // through to the coherence point, never served from a non-coherent cache), the flags likewise, ordered by vmcnt(0) + the
-            // workgroup barrier.  The partner has the same thread -> element map: slot (i * 512 + tid), no layout arithmetic.
-            const int half = mode - 1;
-            if (half) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { const f32x4 t = acc[n][m]; acc[n][m] = acc[n][m + 4]; acc[n][m + 4] = t; }
-            }
-            unsigned long long* wsend = reinterpret_cast<unsigned long long*>(split_ws) + (size_t)(split_idx * 2 + half) * (512 * 32);
-            const unsigned long long* wrecv = reinterpret_cast<const unsigned long long*>(split_ws) + (size_t)(split_idx * 2 + (half ^ 1)) * (512 * 32);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f32x4 v = acc[n][4 + m];
-                    unsigned long long* q = wsend + (size_t)((n * 4 + m) * 2) * 512 + tid;
-                    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(q + 512, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's partials have reached the coherence point
-            __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_store(split_flags + split_idx * 2 + half, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (__hip_atomic_load(split_flags + split_idx * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(8);
-            }
-            __syncthreads();
-            // Receive in two batches of 8 x 16 bytes, each behind ONE wait.  As relaxed atomics hipcc waits for every load before it
-            // issues the next (64 round trips in a row: most of the exchange's first cost of 15-20 us); the loads are therefore plain
-            // `global_load_dwordx4 ... sc1` from inline asm (same cache policy as the agent-scope atomic: read at the coherence point),
-            // and the wait names the destination registers as read-write operands so that nothing can touch them before it.
-#pragma unroll
-            for (int n = 0; n < 4; n += 2) {
-                f32x4 pv[2][4];
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        // slot layout of the sender: 64-bit pairs (2 i) * 512 + tid and (2 i + 1) * 512 + tid -> two 8-byte halves, not
-                        // one 16-byte unit: two dwordx2 loads into the halves of one register quad
-                        const unsigned long long* q = wrecv + (size_t)(((n + nn) * 4 + m) * 2) * 512 + tid + 256;   // +-2048 B: 13-bit offsets
-                        asm volatile("global_load_dwordx2 %0, %2, off offset:-2048 sc1\n\tglobal_load_dwordx2 %1, %2, off offset:2048 sc1"
-                                     : "=&v"(*reinterpret_cast<u64x1*>(&pv[nn][m])), "=&v"(*(reinterpret_cast<u64x1*>(&pv[nn][m]) + 1)) : "v"(q) : "memory");
-                    }
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(pv[0][0]), "+v"(pv[0][1]), "+v"(pv[0][2]), "+v"(pv[0][3]), "+v"(pv[1][0]), "+v"(pv[1][1]), "+v"(pv[1][2]), "+v"(pv[1][3])
-                             :: "memory");
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[n + nn][m] += pv[nn][m];   // (a + b == b + a bitwise: the order of the K halves does not matter)
-            }
-            mshift = 4 * half;
-            kpass = 2;
-        }
-
+        const int kpass = halfu ? 2 : 4;                       // epilogue passes of 2 m-tiles per wave row (a half unit has 4 m-tiles)
         // Epilogue through the 32 KB C stage in 4 passes of 64 rows (m-tiles 2k, 2k+1 of both wave rows): bias / GELU in registers,
         // bf16 rows staged with the 16-byte chunk XOR-swizzled by the row (the 16 rows a ds_write touches would otherwise share
         // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual is added on the way
@@ -636,7 +669,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         if (LNF) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                int row = cm0 + wm * 128 + (m + mshift) * 16 + c;
+                int row = cm0 + wm * wrows + m * 16 + c;
                 row = row < M ? row : M - 1;
                 const float2 st = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
                 mu[m] = st.x; rs[m] = st.y;
@@ -662,21 +695,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             gam0 = ld4(ln.ln_g + my_col); gam1 = ld4(ln.ln_g + my_col + 4);
             bet0 = ld4(ln.ln_b + my_col); bet1 = ld4(ln.ln_b + my_col + 4);
         }
-        auto load_res = [&](int k, int ms) {
+        auto load_res = [&](int k) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
-                const int lrow = (prow >> 5) * 128 + (2 * k + ms + ((prow >> 4) & 1)) * 16 + (prow & 15);
+                const int lrow = (prow >> 5) * wrows + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 int row = cm0 + lrow, col = cn0 + ch * 8;
                 row = row < M ? row : M - 1; col = col < N ? col : 0;         // clamped: loaded, not used
                 rnext[i] = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
                 if (EPI == BEPI_RES_LN) snext[i] = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
             }
         };
-        if (RESV && kpass > 0) load_res(0, mshift);
+        if (RESV) load_res(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (k >= kpass) break;                            // workgroup-uniform: a split tile's workgroup finalises 4 of its 8 m-tiles
+            if (k >= kpass) break;                            // workgroup-uniform
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 const int m = 2 * k + mm;
@@ -705,34 +738,56 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             if (RESV) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { rcur[i] = rnext[i]; scur[i] = snext[i]; }
-                if (k + 1 < kpass) load_res(k + 1, mshift);
+                if (k + 1 < kpass) load_res(k + 1);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
-                const int lrow = (prow >> 5) * 128 + (2 * k + mshift + ((prow >> 4) & 1)) * 16 + (prow & 15);
+                const int lrow = (prow >> 5) * wrows + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 const int row = cm0 + lrow, col = cn0 + ch * 8;
                 const bool inb = row < M && col < N;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
+                // The read-out side works on PAIRS with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: fine in an epilogue, an
+                // anti-lever beside MFMAs): epilogue 5 was ~2200 VALU instructions per wave and tile more than epilogue 0, ~9 us of the
+                // 17 us an out-proj tile spent outside its K loop.  A bf16 pair sits in one dword: lo << 16 and hi & 0xffff0000 are
+                // the two fp32 values.
+                u32x4 vw = *reinterpret_cast<const u32x4*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
                 if (RESV) {
-                    const bf16x8 r8 = rcur[i];
-                    const float gam[8] = {gam0.x, gam0.y, gam0.z, gam0.w, gam1.x, gam1.y, gam1.z, gam1.w};
-                    const float bet[8] = {bet0.x, bet0.y, bet0.z, bet0.w, bet1.x, bet1.y, bet1.z, bet1.w};
+                    const u32x4 rw = __builtin_bit_cast(u32x4, rcur[i]);
+                    // LayerNorm of the residual row: (r - mean) rstd gamma + beta = (r a + b) gamma + beta with a = rstd, b = -mean rstd
+                    const float ra = scur[i].y, rb = -scur[i].x * scur[i].y;
+                    const f32x2 gam2[4] = {{gam0.x, gam0.y}, {gam0.z, gam0.w}, {gam1.x, gam1.y}, {gam1.z, gam1.w}};
+                    const f32x2 bet2[4] = {{bet0.x, bet0.y}, {bet0.z, bet0.w}, {bet1.x, bet1.y}, {bet1.z, bet1.w}};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float r = (float)r8[j];
-                        if (EPI == BEPI_RES_LN) r = fmaf((r - scur[i].x) * scur[i].y, gam[j], bet[j]);   // LayerNorm of the residual row
-                        v[j] = (bf16_t)((float)v[j] + r);
+                    for (int q = 0; q < 4; ++q) {
+                        f32x2 x = {__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)};
+                        f32x2 r = {__uint_as_float(rw[q] << 16), __uint_as_float(rw[q] & 0xffff0000u)};
+                        if (EPI == BEPI_RES_LN) {
+                            r = __builtin_elementwise_fma(r, (f32x2){ra, ra}, (f32x2){rb, rb});
+                            r = __builtin_elementwise_fma(r, gam2[q], bet2[q]);
+                        }
+                        x = x + r;
+                        const bf16x2 o = {(bf16_t)x[0], (bf16_t)x[1]};
+                        vw[q] = __builtin_bit_cast(unsigned, o);
                     }
                 }
-                if (inb) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = v;
+                if (inb) *reinterpret_cast<u32x4*>(C + (int64_t)row * ldc + col) = vw;
                 if (EPI == BEPI_RES_LN && ln.stats_out) {
-                    // (sum, sum of squares) of the row's 256 bf16 outputs in this tile: the row's 32 chunks sit in 32 consecutive lanes
-                    float s1 = 0.f, s2 = 0.f;
+                    // (sum, M2 = sum of squared deviations from the TILE's mean) of the row's 256 bf16 outputs in this tile (N % 256 == 0
+                    // for this epilogue: every tile has 256 valid columns); the row's 32 chunks sit in 32 consecutive lanes.  Deviations
+                    // from the tile mean, not raw squares: E[x^2] - mean^2 in fp32 loses the variance of a row whose mean is large
+                    // against its spread (outlier hidden dimensions of trained checkpoints); ln_rowstat merges the tiles exactly (Chan).
+                    // (rows beyond M compute garbage that is never stored)
+                    f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float x = (inb && col + j < N) ? (float)v[j] : 0.f; s1 += x; s2 = fmaf(x, x, s2); }
-                    s1 = half_wave_sum(s1);
-                    s2 = half_wave_sum(s2);
+                    for (int q = 0; q < 4; ++q) s1p += (f32x2){__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)};
+                    const float s1 = half_wave_sum(s1p[0] + s1p[1]);
+                    const float tmean = s1 * (1.0f / 256.0f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 d = (f32x2){__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)} - (f32x2){tmean, tmean};
+                        s2p = __builtin_elementwise_fma(d, d, s2p);
+                    }
+                    const float s2 = half_wave_sum(s2p[0] + s2p[1]);
                     if (ch == 0 && row < M)
                         *reinterpret_cast<float2*>(ln.stats_out + ((int64_t)row * tiles_n + (cn0 >> 8)) * 2) = make_float2(s1, s2);
                 }
@@ -745,36 +800,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 
 template <int EPI>
 static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
-                     int N, int K, hipStream_t st, GemmSplitWs* sp, const BfEpiLn* lnp = nullptr) {
-    const size_t shmem = (size_t)2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
-    static bool attr_set = false;
-    if (!attr_set) {
-        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
+                     int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
+    const int shmem = 2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
+    DeviceInfo di;
+    MGEA_TRY(device_info(&di));
+    static uint64_t attr_done = 0;                      // per instantiation, one bit per device
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI>), shmem, di.dev, &attr_done));
     const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        MGEA_CHECK_HIP(hipGetDevice(&dev));
-        MGEA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount / 8 * 8;
-    }
+    const int n_cu = di.n_cu / 8 * 8;
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
-    // split-tail scratch (see the kernel): 4 KB of flags, then one 256 KB accumulator image per pair of workgroups
-    static const int split_min_kt = getenv("MGEA_BF16_GEMM_SPLIT_MIN_KT") ? atoi(getenv("MGEA_BF16_GEMM_SPLIT_MIN_KT")) : 32;   // K >= 2048 (A/B hook)
-    float4* ws = nullptr;
-    int* flags = nullptr;
-    int epoch = 0;
-    if (sp && sp->buf && sp->bytes >= 4096 + (size_t)(grid / 2) * 512 * 32 * 16 && grid / 2 <= 1024 && !getenv("MGEA_BF16_GEMM_NOSPLIT")) {
-        flags = (int*)sp->buf;
-        ws = (float4*)((char*)sp->buf + 4096);
-        epoch = ++sp->epoch;                                               // flags never need clearing: they are compared with the launch's epoch
+    const int tail = tune(TUNE_BF16_GEMM_TAIL);
+    if (info) {   // what the kernel will do with the tiles left after the full rounds (the same arithmetic as in the kernel, XCD run 0)
+        const int wg_x = grid / 8, per_x = (n_tiles + 7) / 8 < n_tiles ? (n_tiles + 7) / 8 : n_tiles;
+        const int rem = per_x - per_x / wg_x * wg_x;
+        info->kernel = 2;
+        info->half_tiles = (tail != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
     }
     hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
-                       ws, flags, epoch, split_min_kt, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
+                       tail, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -785,48 +828,45 @@ static int launch_glds(const bf16_t* a, int lda, const bf16_t* w, int ldw, const
     constexpr int BM = 128 * WMW, BN = 64 * NT;
     constexpr int NS = (NT == 2 && WMW == 2) ? 3 : 2;
     constexpr size_t ring = (size_t)NS * (BM + BN) * 128, stage_c = (size_t)BM * (BN * 2 + 16);
-    const size_t shmem = ring > stage_c ? ring : stage_c;      // 64 KB .. 144 KB of the 160 KB LDS
-    static bool attr_set = false;   // one per instantiation
-    if (!attr_set) {
-        MGEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<EPI, NT, WMW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
+    const int shmem = (int)(ring > stage_c ? ring : stage_c);      // 64 KB .. 144 KB of the 160 KB LDS
+    DeviceInfo di;
+    MGEA_TRY(device_info(&di));
+    static uint64_t attr_done = 0;   // one per instantiation
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<EPI, NT, WMW>), shmem, di.dev, &attr_done));
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
-    const char* e = getenv("MGEA_BF16_GEMM_DBG");   // tools/gemm_bf16_bench.py ablations only
-    const int dbg = e ? (atoi(e) & 3) : 0;
     hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, NT, WMW>), dim3(tm * tn), dim3(256 * WMW), shmem, st, a, lda, w, ldw, bias,
-                       r, c, ldc, M, N, K, tn | (dbg << 16));
+                       r, c, ldc, M, N, K, tn);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
 
+// which kernel runs a shape: 0 the register-staged 128 x 128 kernel, 1 a ring kernel, 2 the persistent phase-interleaved 256 x 256 kernel
+static int pick_bf16_kernel(int M, int N, int K, int ldc) {
+    if (!(M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && K % 64 == 0) || tune(TUNE_BF16_GEMM_SMALL)) return 0;
+    const int force = tune(TUNE_BF16_GEMM_TILE);
+    const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
+    // 256-wide N tiles unless that leaves too few workgroups for 256 CUs
+    return (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256)) ? 2 : 1;
+}
+
 template <int EPI>
 static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
-                            int ldc, int M, int N, int K, hipStream_t st, GemmSplitWs* sp) {
-    const char* e = getenv("MGEA_BF16_GEMM_TILE");   // 1: 128x128 / 2: 256x128 / 3: 256x256 (tools/gemm_bf16_bench.py)
-    const int force = e ? atoi(e) : 0;
+                            int ldc, int M, int N, int K, hipStream_t st, GemmBf16Info* info) {
+    const int force = tune(TUNE_BF16_GEMM_TILE);   // 1: 128x128 / 2: 256x128 / 3: 256x256 ring kernels (tools/gemm_bf16_bench.py)
+    if (pick_bf16_kernel(M, N, K, ldc) == 2) return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info);
+    if (info) { info->kernel = 1; info->half_tiles = 0; }
     if (force == 1) return launch_glds<EPI, 2, 1>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     if (force == 2) return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     if (force == 3) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
-    // 256-wide N tiles unless that leaves too few workgroups for 256 CUs (N = 768 projections)
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
-    if (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256))   // the phase-interleaved persistent 256 x 256 kernel
-        return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
     if (N % 256 == 0 && blocks256 >= 512) return launch_glds<EPI, 4, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     return launch_glds<EPI, 2, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
 }
 
-bool gemm_bf16_is_persistent(int M, int N, int K) {
-    const char* e = getenv("MGEA_BF16_GEMM_TILE");
-    const int force = e ? atoi(e) : 0;
-    if (!(M >= 512 && N >= 128 && N % 8 == 0 && K % 64 == 0) || getenv("MGEA_BF16_GEMM_SMALL")) return false;
-    const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
-    return force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256);
-}
+bool gemm_bf16_is_persistent(int M, int N, int K) { return pick_bf16_kernel(M, N, K, 8) == 2; }
 
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* sp, const BfEpiLn* lnp) {
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
     if (epi >= BEPI_LNFOLD) {   // LayerNorm folded around the GEMM: the persistent kernel only
@@ -838,19 +878,20 @@ int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
         if (epi == BEPI_RES_LN) {
             MGEA_REQUIRE(res && lnp->rowstat && lnp->ln_g && lnp->ln_b, MGEA_EINVAL,
                          "bf16 gemm: RES_LN without residual / row statistics / gamma / beta (identity tables for a normalised residual)");
-            return launch_ph<BEPI_RES_LN>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
+            return launch_ph<BEPI_RES_LN>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
         }
         MGEA_REQUIRE(lnp->rowstat && lnp->c1, MGEA_EINVAL, "bf16 gemm: LNFOLD without row statistics / c1");
-        if (epi == BEPI_LNFOLD) return launch_ph<BEPI_LNFOLD>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
-        return launch_ph<BEPI_LNFOLD_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp, lnp);
+        if (epi == BEPI_LNFOLD) return launch_ph<BEPI_LNFOLD>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+        return launch_ph<BEPI_LNFOLD_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
     }
-    if (M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && !getenv("MGEA_BF16_GEMM_SMALL")) {
+    if (pick_bf16_kernel(M, N, K, ldc) != 0) {
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
         bf16_t* c = (bf16_t*)C;
-        if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
-        if (epi == BEPI_BIAS_GELU) return launch_glds_pick<BEPI_BIAS_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
-        if (epi == BEPI_BIAS_RES && res) return launch_glds_pick<BEPI_BIAS_RES>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, sp);
+        if (epi == BEPI_BIAS) return launch_glds_pick<BEPI_BIAS>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info);
+        if (epi == BEPI_BIAS_GELU) return launch_glds_pick<BEPI_BIAS_GELU>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info);
+        if (epi == BEPI_BIAS_RES && res) return launch_glds_pick<BEPI_BIAS_RES>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info);
     }
+    if (info) { info->kernel = 0; info->half_tiles = 0; }
     const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
     dim3 grid(tm * tn), block(256);
     const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W, *r = (const bf16_t*)res;
@@ -870,19 +911,24 @@ int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
 
 // ------------------------------------------------------------------------------------------
 // Helpers of the folded-LayerNorm pipeline (BfEpiLn).
-// (mean, rstd) per row from the per-tile (sum, sum of squares) the RES_LN epilogue left; the last subtraction in double.
+// (mean, rstd) per row from the per-tile (sum, M2 about the tile's own mean) pairs the RES_LN epilogue left, each over C / n_part
+// columns: mean = sum of sums / C, M2 = sum_i M2_i + cnt sum_i (mean_i - mean)^2 (the exact pairwise merge), in double.
 // A launch of its own (5 us): deriving the statistics inside the consumers instead (8-16 more loaded values live per lane in their
 // epilogues) pushed 20-50 registers of the persistent kernel to scratch and cost 0.45 ms per forward.
 __global__ void ln_rowstat_kernel(const float* __restrict__ part, float* __restrict__ rowstat, int M, int n_part, int C, float eps) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < n_part; ++i) { s1 += part[((int64_t)row * n_part + i) * 2]; s2 += part[((int64_t)row * n_part + i) * 2 + 1]; }
+    const double cnt = (double)C / n_part;
+    double s1 = 0.0;
+    for (int i = 0; i < n_part; ++i) s1 += part[((int64_t)row * n_part + i) * 2];
     const double mean = s1 / C;
-    double var = s2 / C - mean * mean;
-    var = var > 0.0 ? var : 0.0;
+    double m2 = 0.0;
+    for (int i = 0; i < n_part; ++i) {
+        const double d = part[((int64_t)row * n_part + i) * 2] / cnt - mean;
+        m2 += part[((int64_t)row * n_part + i) * 2 + 1] + cnt * d * d;
+    }
     rowstat[(int64_t)row * 2] = (float)mean;
-    rowstat[(int64_t)row * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    rowstat[(int64_t)row * 2 + 1] = (float)(1.0 / sqrt(m2 / C + (double)eps));
 }
 int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st) {
     hipLaunchKernelGGL(ln_rowstat_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, part, rowstat, M, n_part, C, eps);
@@ -1323,7 +1369,10 @@ void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict_
             bf16_t* so = reinterpret_cast<bf16_t*>(lds + stage * STAGE) + wave * (32 * 64);   // [32 queries][64 d], chunk ^= query & 7
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq) {
-                const float inv = __builtin_amdgcn_rcpf(lacc[mq][0]);   // 1 ulp, far below the bf16 output rounding
+                // 1 ulp, far below the bf16 output rounding; a row without ANY valid key (all-zero mask) has lacc == 0 and oacc == 0:
+                // it gets zeros, not rcp(0) * 0 = NaN (the reference's finfo.min mask would attend uniformly to padding there --
+                // an input the tokenizer never produces: [CLS] is always valid)
+                const float inv = lacc[mq][0] > 0.f ? __builtin_amdgcn_rcpf(lacc[mq][0]) : 0.f;
                 const int ql = mq * 16 + c;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -1358,19 +1407,12 @@ int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int
     const int64_t n_items = (int64_t)B * H * nqb;
     MGEA_REQUIRE(n_items < (1 << 30), MGEA_EINVAL, "bf16 attention: too many (batch, head, query block) items");
     MGEA_REQUIRE((int64_t)T * 6 * H * dh < ((int64_t)1 << 32), MGEA_EINVAL, "bf16 attention: one sequence of qkv rows must span < 4 GB");
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        MGEA_CHECK_HIP(hipGetDevice(&dev));
-        MGEA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount;
-    }
+    DeviceInfo di;
+    MGEA_TRY(device_info(&di));
+    const int n_cu = di.n_cu;
     const int shmem = 2 * 2048 * 16 + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MGEA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
-        attr_set = true;
-    }
+    static uint64_t attr_done = 0;
+    MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel, shmem, di.dev, &attr_done));
     const int grid = (int)(n_items < 2 * n_cu ? n_items : 2 * n_cu);
     hipLaunchKernelGGL(attn_bf16_kernel, dim3(grid), dim3(256), shmem, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
                        (int)n_items, nqb, 1.0f / sqrtf((float)dh));

@@ -1,6 +1,11 @@
 // C-ABI glue: error string, device probe, LoRA fold and the op-level entry points the parity
 // tests use to check each kernel against the oracle in isolation (include/mgea.h).
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -13,6 +18,57 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+// ---- switches: one table, initialised from the environment when the library is loaded ---------
+namespace {
+struct TuneEntry { const char* name; const char* env; int dflt; };
+const TuneEntry kTune[TUNE_COUNT] = {
+    {"bf16_gemm_tile", "MGEA_BF16_GEMM_TILE", 0},     {"bf16_gemm_small", "MGEA_BF16_GEMM_SMALL", 0},
+    {"bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},     {"bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
+    {"decoder_unfused", "MGEA_DECODER_UNFUSED", 0},   {"decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
+    {"decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},
+};
+std::atomic<int> g_tune[TUNE_COUNT];
+struct TuneInit {
+    TuneInit() {
+        for (int i = 0; i < TUNE_COUNT; ++i) {
+            const char* e = getenv(kTune[i].env);
+            g_tune[i].store(e && e[0] ? atoi(e) : kTune[i].dflt, std::memory_order_relaxed);
+        }
+    }
+} g_tune_init;
+int tune_index(const char* name) {
+    for (int i = 0; name && i < TUNE_COUNT; ++i)
+        if (!strcmp(name, kTune[i].name)) return i;
+    return -1;
+}
+}  // namespace
+int tune(int key) { return g_tune[key].load(std::memory_order_relaxed); }
+
+int device_info(DeviceInfo* out) {
+    static std::mutex mu;
+    static int n_cu[64] = {0};
+    int dev = 0;
+    MGEA_CHECK_HIP(hipGetDevice(&dev));
+    MGEA_REQUIRE(dev >= 0 && dev < 64, MGEA_EINVAL, "device id %d out of range", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        MGEA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu[dev] = prop.multiProcessorCount;
+    }
+    out->dev = dev;
+    out->n_cu = n_cu[dev];
+    return MGEA_OK;
+}
+int set_max_dynamic_lds(const void* fn, int bytes, int dev, uint64_t* done) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (*done >> dev & 1) return MGEA_OK;
+    MGEA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    *done |= (uint64_t)1 << dev;
+    return MGEA_OK;
+}
 }  // namespace mgea
 
 using namespace mgea;
@@ -21,6 +77,19 @@ extern "C" {
 
 const char* mgea_last_error(void) { return get_error(); }
 int mgea_version(void) { return 100; }
+
+int mgea_tune_set(const char* name, int32_t value) {
+    const int i = tune_index(name);
+    MGEA_REQUIRE(i >= 0, MGEA_EINVAL, "tune_set: unknown switch '%s'", name ? name : "(null)");
+    g_tune[i].store(value, std::memory_order_relaxed);
+    return MGEA_OK;
+}
+int mgea_tune_get(const char* name, int32_t* value_out) {
+    const int i = tune_index(name);
+    MGEA_REQUIRE(i >= 0 && value_out, MGEA_EINVAL, "tune_get: unknown switch '%s'", name ? name : "(null)");
+    *value_out = tune(i);
+    return MGEA_OK;
+}
 
 int mgea_device_count(void) {
     int n = 0;
@@ -75,16 +144,28 @@ int mgea_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_de
     return launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream);
 }
 
-int64_t mgea_op_gemm_bf16_scratch_bytes(void) { return (int64_t)MGEA_GEMM_SPLIT_WS_BYTES; }
-
-int mgea_op_gemm_bf16_split(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev, void* out_dev,
-                            int32_t M, int32_t N, int32_t K, int32_t epi, void* scratch_dev, int64_t scratch_bytes,
-                            int32_t* epoch_io, void* stream) {
-    MGEA_REQUIRE(a_dev && w_dev && out_dev && scratch_dev && epoch_io, MGEA_EINVAL, "op_gemm_bf16_split: NULL argument");
-    GemmSplitWs sp{scratch_dev, (size_t)scratch_bytes, *epoch_io};
-    const int rc = launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream, &sp);
-    *epoch_io = sp.epoch;
+int mgea_op_gemm_bf16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const void* res_dev, void* out_dev,
+                         int32_t M, int32_t N, int32_t K, int32_t epi, const float* rowstat_dev, const float* c1_dev,
+                         const float* ln_g_dev, const float* ln_b_dev, float* stats_out_dev, int32_t* info_out, void* stream) {
+    MGEA_REQUIRE(a_dev && w_dev && out_dev, MGEA_EINVAL, "op_gemm_bf16_ln: NULL argument");
+    const BfEpiLn ln{rowstat_dev, c1_dev, ln_g_dev, ln_b_dev, stats_out_dev};
+    GemmBf16Info gi{-1, 0};
+    const int rc = launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream, &gi,
+                                    epi >= 3 ? &ln : nullptr);
+    if (info_out) { info_out[0] = gi.kernel; info_out[1] = gi.half_tiles; }
     return rc;
+}
+
+int mgea_op_ln_rowstat(const float* part_dev, float* rowstat_dev, int32_t M, int32_t n_part, int32_t C, float eps, void* stream) {
+    MGEA_REQUIRE(part_dev && rowstat_dev && M > 0 && n_part > 0 && C > 0 && C % n_part == 0, MGEA_EINVAL, "op_ln_rowstat: bad argument");
+    return launch_ln_rowstat(part_dev, rowstat_dev, M, n_part, C, eps, (hipStream_t)stream);
+}
+
+int mgea_op_fold_ln_bf16(const float* w_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, int32_t N, int32_t K,
+                         void* wf_out_dev, float* c1_out_dev, float* c2_out_dev, void* stream) {
+    MGEA_REQUIRE(w_dev && gamma_dev && beta_dev && bias_dev && wf_out_dev && c1_out_dev && c2_out_dev && N > 0 && K > 0, MGEA_EINVAL,
+                 "op_fold_ln_bf16: bad argument");
+    return launch_fold_ln_weights_bf16(w_dev, gamma_dev, beta_dev, bias_dev, wf_out_dev, c1_out_dev, c2_out_dev, N, K, (hipStream_t)stream);
 }
 
 int mgea_op_attention_bf16(const void* qkv_dev, const int32_t* mask_dev, void* out_dev, int32_t B, int32_t T,

@@ -37,6 +37,23 @@ const char* get_error();
         if (_rc != MGEA_OK) return _rc; \
     } while (0)
 
+// ---- A/B and test switches (tools/README.md) ------------------------------------------------
+// One process-global table, filled ONCE when the library is loaded from the MGEA_<NAME> environment variables and changed at
+// run time only through mgea_tune_set() (tests, tools): nothing on a launch path reads the environment.
+enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 256x128 / 3 256x256 ring kernels; 4 = the persistent 256x256 kernel
+       TUNE_BF16_GEMM_SMALL,      // 1: the register-staged 128x128 kernel for every shape
+       TUNE_BF16_GEMM_TAIL,       // persistent kernel, tiles left after the full rounds: 0 whole tiles, 1 two 128-row halves, 2 = 1 + staggered order
+       TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
+       TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
+       TUNE_COUNT };
+int tune(int key);
+
+// per-device facts the launchers need (cached per device id; one process may drive several devices)
+struct DeviceInfo { int dev; int n_cu; };
+int device_info(DeviceInfo* out);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): `done` is the instantiation's own bit mask
+int set_max_dynamic_lds(const void* fn, int bytes, int dev, uint64_t* done);
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -202,17 +219,16 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st);
 //   epi 3 / 4 (LNFOLD / +GELU): A = RAW rows, W = W diag(gamma) in bf16, c1[n] = sum_k W'[n, k], bias slot = c2 = b + W beta;
 //                               rowstat = (mean, rstd) of the A rows, [M][2]; out = rstd (A W'^T - mean c1) + c2
 //   epi 5 (RES_LN): out = A W^T + bias + LayerNorm(res row) with the residual's rowstat / ln_g / ln_b (an already normalised
-//                   residual comes with identity tables: mean 0, rstd 1, gamma 1, beta 0); stats_out (or nullptr) receives (sum, sum
-//                   of squares) of every output row per 256-column tile, [M][N / 256][2], from which launch_ln_rowstat makes the
-//                   next (mean, rstd).
+//                   residual comes with identity tables: mean 0, rstd 1, gamma 1, beta 0); stats_out (or nullptr) receives (sum, M2 =
+//                   sum of squared deviations from the tile's own mean) of every output row per 256-column tile, [M][N / 256][2],
+//                   from which launch_ln_rowstat makes the next (mean, rstd).
 struct BfEpiLn { const float* rowstat; const float* c1; const float* ln_g; const float* ln_b; float* stats_out; };
-// Scratch for the persistent bf16 GEMM's split-tail schedule (bf16.hip): 4 KB of flags + one 256 KB fp32 accumulator image per pair
-// of workgroups.  Owned by ONE engine / stream (launches that share it must be stream-ordered); epoch is bumped per launch so the
-// flags never need clearing.  nullptr: every tile is computed whole by one workgroup.
-struct GemmSplitWs { void* buf; size_t bytes; int epoch; };
-constexpr size_t MGEA_GEMM_SPLIT_WS_BYTES = 4096 + (size_t)128 * 512 * 32 * 16;   // up to 256 persistent workgroups
+// What a launch_gemm_bf16 call ran (optional out-parameter; the engines count these for mgea_bert_stats): kernel 0 = the
+// register-staged 128 x 128 kernel, 1 = a ring kernel, 2 = the persistent phase-interleaved 256 x 256 kernel; half_tiles = 1 when that
+// kernel cuts the tiles left over after its full rounds into two 128-row halves (bf16.hip, "HALF-TILE TAIL").
+struct GemmBf16Info { int kernel; int half_tiles; };
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmSplitWs* split = nullptr, const BfEpiLn* ln = nullptr);
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info = nullptr, const BfEpiLn* ln = nullptr);
 // true when launch_gemm_bf16 would run this shape on the persistent 256 x 256 kernel (the only one with epilogues 3-5)
 bool gemm_bf16_is_persistent(int M, int N, int K);
 int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st);

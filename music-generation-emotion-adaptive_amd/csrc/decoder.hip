@@ -716,14 +716,9 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     arena_layout(*cfg, &h->off, &total);
     h->arena_total = total;
     h->dh = cfg->d_model / cfg->n_head;
-    {
-        const char* e = getenv("MGEA_DECODER_UNFUSED");
-        h->force_unfused = e && e[0] == '1';
-        const char* gv = getenv("MGEA_DECODER_NOGEMV");
-        h->no_gemv = gv && gv[0] == '1';
-        const char* g = getenv("MGEA_DECODER_NOGRAPH");
-        h->no_graph = g && g[0] == '1';
-    }
+    h->force_unfused = tune(TUNE_DECODER_UNFUSED) == 1;   // A/B switches (tools/README.md), latched per engine
+    h->no_gemv = tune(TUNE_DECODER_NOGEMV) == 1;
+    h->no_graph = tune(TUNE_DECODER_NOGRAPH) == 1;
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
     h->kv.n_pages = cfg->max_batch * h->pages_per_row_cap;

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "mgea_last_error": (C.c_char_p, []),
     "mgea_version": (C.c_int, []),
     "mgea_device_count": (C.c_int, []),
+    "mgea_tune_set": (C.c_int, [C.c_char_p, _I32]),
+    "mgea_tune_get": (C.c_int, [C.c_char_p, C.POINTER(_I32)]),
     "mgea_decoder_arena_layout": (C.c_int, [C.POINTER(DecoderConfig), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
     "mgea_decoder_create": (C.c_int, [C.POINTER(DecoderConfig), _P, C.POINTER(_P)]),
     "mgea_decoder_destroy": (C.c_int, [_P]),
@@ -64,6 +66,7 @@ PROTOTYPES = {
     "mgea_bert_create": (C.c_int, [C.POINTER(BertConfig), _P, C.POINTER(_P)]),
     "mgea_bert_destroy": (C.c_int, [_P]),
     "mgea_bert_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
+    "mgea_bert_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "mgea_lora_merge": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "mgea_op_gemm_workspace_floats": (_I64, [_I32, _I32, _I32]),
     "mgea_op_gemm_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
@@ -71,8 +74,9 @@ PROTOTYPES = {
     "mgea_op_attention_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "mgea_op_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "mgea_op_gemm_bf16_scratch_bytes": (C.c_int64, []),
-    "mgea_op_gemm_bf16_split": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, C.c_int64, C.POINTER(C.c_int32), _P]),
+    "mgea_op_gemm_bf16_ln": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(_I32), _P]),
+    "mgea_op_ln_rowstat": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _P]),
+    "mgea_op_fold_ln_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "mgea_op_attention_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "mgea_op_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
     "mgea_op_tiled_weight_floats": (C.c_int64, [_I32, _I32]),
@@ -106,6 +110,19 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def tune_get(name: str) -> int:
+    v = _I32(0)
+    check(load().mgea_tune_get(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def tune_set(name: str, value: int) -> int:
+    """Set an A/B switch of the native library (tools/README.md); returns the previous value."""
+    old = tune_get(name)
+    check(load().mgea_tune_set(name.encode(), int(value)))
+    return old
 
 
 def last_error() -> str:

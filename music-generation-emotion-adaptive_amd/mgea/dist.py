@@ -54,6 +54,17 @@ def all_reduce_max(value: float, device) -> float:
     return float(t.item())
 
 
+def all_gather_floats(value: float, device) -> List[float]:
+    """every rank's host scalar, in rank order, on every rank (bench.py: per-rank tokens/s, so a straggler shows in the line)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [float(b.item()) for b in bufs]
+
+
 def shard_rows(n_rows: int, rank: int, world: int) -> range:
     """Contiguous batch slice of rank `rank` (prompts are independent: no data-path collective).
     Remainder rows go to the lowest ranks."""

@@ -56,33 +56,61 @@ def attention(qkv: torch.Tensor, n_head: int, lens: Optional[torch.Tensor] = Non
     return out
 
 
-class GemmScratch:
-    """Scratch + launch counter for the split-tail schedule of the persistent bf16 GEMM (include/mgea.h); one per stream."""
-
-    def __init__(self, device="cuda"):
-        lib = _lib.load()
-        self.buf = torch.zeros(int(lib.mgea_op_gemm_bf16_scratch_bytes()), dtype=torch.uint8, device=device)
-        self.epoch = C.c_int32(0)
-
-
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-              gelu: bool = False, scratch: Optional["GemmScratch"] = None) -> torch.Tensor:
+              gelu: bool = False, ln: Optional[dict] = None, info: Optional[list] = None, out: Optional[torch.Tensor] = None):
     """bf16 perf-mode GEMM: (a [M,K] bf16) @ (w [N,K] bf16)^T + bias (fp32) [+GELU | +res (bf16)] -> bf16.
-    scratch: let the persistent kernel split its left-over tiles across two workgroups (what BertEngine does)."""
+    ln (persistent 256 x 256 kernel only) selects a LayerNorm-folding epilogue of the big-batch DistilBERT pipeline (mgea.h):
+      dict(rowstat=[M,2], c1=[N])                      -> epi 3 / 4 (gelu): rstd (a w'^T - mean c1) + bias, bias = c2
+      dict(rowstat=[M,2], g=[N], b=[N], stats=True)    -> epi 5: a w^T + bias + LN(res); returns (out, per-tile (sum, M2) [M, N/256, 2])
+    info: a list that receives [kernel, half_tiles] of the launch."""
     lib = _lib.load()
     a, w = _dev(a.to(torch.bfloat16)), _dev(w.to(torch.bfloat16))
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     b = None if bias is None else _dev(bias.float())
     r = None if res is None else _dev(res.to(torch.bfloat16))
     epi = 2 if res is not None else (1 if gelu else 0)
-    if scratch is not None:
-        check(lib.mgea_op_gemm_bf16_split(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, ptr(scratch.buf),
-                                          scratch.buf.numel(), C.byref(scratch.epoch), stream_ptr()))
-        return out
-    check(lib.mgea_op_gemm_bf16(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, stream_ptr()))
+    rowstat = c1 = g = be = stats = None
+    if ln is not None:
+        rowstat = _dev(ln["rowstat"].float())
+        if "c1" in ln:
+            epi, c1 = (4 if gelu else 3), _dev(ln["c1"].float())
+        else:
+            epi, g, be = 5, _dev(ln["g"].float()), _dev(ln["b"].float())
+            if isinstance(ln.get("stats"), torch.Tensor):
+                stats = ln["stats"]                                   # caller's [M, N/256, 2] fp32 buffer (benchmarks: no allocation per call)
+            elif ln.get("stats"):
+                stats = torch.zeros(M, N // 256, 2, dtype=torch.float32, device=a.device)
+    io = (C.c_int32 * 2)(-1, -1)
+    check(lib.mgea_op_gemm_bf16_ln(ptr(a), ptr(w), ptr(b), ptr(r), ptr(out), M, N, K, epi, ptr(rowstat), ptr(c1), ptr(g), ptr(be),
+                                   ptr(stats), io, stream_ptr()))
+    if info is not None:
+        info[:] = [int(io[0]), int(io[1])]
+    return (out, stats) if stats is not None else out
+
+
+def ln_rowstat(part: torch.Tensor, C_: int, eps: float) -> torch.Tensor:
+    """per-tile (sum, M2) [M, n_part, 2] -> (mean, rstd) [M, 2] of rows of C_ columns."""
+    lib = _lib.load()
+    part = _dev(part.float())
+    M, n_part = part.shape[0], part.shape[1]
+    out = torch.empty(M, 2, dtype=torch.float32, device=part.device)
+    check(lib.mgea_op_ln_rowstat(ptr(part), ptr(out), M, n_part, int(C_), float(eps), stream_ptr()))
     return out
+
+
+def fold_ln_bf16(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: torch.Tensor):
+    """-> (bf16(W diag(gamma)) [N,K], c1 [N] = row sums of the rounded product, c2 [N] = bias + W beta)."""
+    lib = _lib.load()
+    w, gamma, beta, bias = _dev(w.float()), _dev(gamma.float()), _dev(beta.float()), _dev(bias.float())
+    N, K = w.shape
+    wf = torch.empty(N, K, dtype=torch.bfloat16, device=w.device)
+    c1 = torch.empty(N, dtype=torch.float32, device=w.device)
+    c2 = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(lib.mgea_op_fold_ln_bf16(ptr(w), ptr(gamma), ptr(beta), ptr(bias), N, K, ptr(wf), ptr(c1), ptr(c2), stream_ptr()))
+    return wf, c1, c2
 
 
 def attention_bf16(qkv: torch.Tensor, n_head: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -27,3 +27,17 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture
+def tune():
+    """Set A/B switches of the native library for one test (mgea_tune_set; tools/README.md) and restore them afterwards."""
+    from mgea import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.tune_set(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for name, old in saved.items():
+        _lib.tune_set(name, old)

@@ -124,6 +124,27 @@ def test_twin_mode_post_ln_relu(golden):
     np.testing.assert_allclose(logits[0].numpy(), g["twin_logits1"], atol=LOGIT_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["tiny8h", "S"])
+def test_twin_mode_at_real_shapes_vs_reference_golden(golden, tag):
+    """generate_music/generate.py:25-61 (post-LN ReLU nn.TransformerEncoder, no mask, whole-sequence recompute per step, the
+    file north_star names) at d_model 256 / 8 heads and at the Decoder-S shape (6L / 512d / 8H, V = 8324): logits of the prompt
+    (decoder_S.npz keeps the first 64 columns) and 8 greedy tokens generated the way `sample` does -- feed the whole sequence,
+    take the argmax of the last position -- against the fixtures tests/golden/make_golden.py wrote from the reference's own
+    lifted GPT class."""
+    g = golden("decoder_" + tag)
+    eng, _, _ = make(g, block_mode="twin")
+    p = g["prompt1"].tolist()
+    want_lg, want_ids = g["twin_logits1"], g["twin_greedy1"].tolist()
+    logits = eng.reset_and_prefill(torch.tensor([p])).cpu().numpy()[0]
+    np.testing.assert_allclose(logits[:, : want_lg.shape[1]], want_lg, atol=LOGIT_TOL, rtol=0)
+    assert np.abs(logits[:, : want_lg.shape[1]] - want_lg).max() < 1e-4       # what fp32 actually achieves
+    ids = list(p)
+    while len(ids) < len(want_ids):
+        lg = eng.reset_and_prefill(torch.tensor([ids])).cpu()
+        ids.append(int(lg[0, -1].argmax()))
+    assert ids == want_ids
+
+
 def test_topk_sampling_stays_in_topk(golden):
     g = golden("decoder_tiny")
     eng, _, _ = make(g)
@@ -352,16 +373,16 @@ def test_fused_path_vs_reference_golden_decoder_s(golden):
 
 
 @pytest.mark.gpu
-def test_single_stream_gemv_path_matches_mfma_path(golden, monkeypatch):
+def test_single_stream_gemv_path_matches_mfma_path(golden, tune):
     """B = 1 (the reference's serving case) runs its projections as wave-level dot products on the row-major weights;
-    MGEA_DECODER_NOGEMV=1 keeps the MFMA kernels.  Same greedy ids over 120 steps (two KV pages), logits within fp32
+    the switch decoder_nogemv (mgea_tune_set) keeps the MFMA kernels.  Same greedy ids over 120 steps (two KV pages), logits within fp32
     summation noise, and the reference-generated golden ids for the first 48."""
     g = golden("decoder_S")
     p = prompts_of(g)[0]
     eng_v, _, _ = make(g, max_batch=2)
-    monkeypatch.setenv("MGEA_DECODER_NOGEMV", "1")
+    tune("decoder_nogemv", 1)
     eng_m, _, _ = make(g, max_batch=2)
-    monkeypatch.delenv("MGEA_DECODER_NOGEMV")
+    tune("decoder_nogemv", 0)
     a = eng_v.generate([p], 120, top_k=1).cpu()
     b = eng_m.generate([p], 120, top_k=1).cpu()
     assert torch.equal(a, b)

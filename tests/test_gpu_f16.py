@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 # observed on MI355X (gpurun_out/r2_t3.log): max |logit diff| 9.9e-4 (Decoder-S, 4 rows x 96 steps) and 1.3e-3 (12L/768d, 3 rows x
 # 72 steps) with 100 % argmax agreement; fp16 has a 2^-11 relative step and the logits are sums of 512-768 products of O(1)
-# activations, so O(1e-3) is the expected scale.  The bound leaves a factor ~8 for other weights / longer contexts.
-F16_LOGIT_TOL = 1e-2
+# activations, so O(1e-3) is the expected scale.  The bound is 3x the worst observation (round 2 had 1e-2: a 5x regression would
+# have passed).
+F16_LOGIT_TOL = 4e-3
 
 
 def rounded(sd):

@@ -1,21 +1,34 @@
 #!/bin/bash
-# One GPU-box cycle: parity tests, a short bench line and the rocprofv3 kernel stats of the bench command.
-# usage (from the repo root, through gpurun): bash tools/gpu_cycle.sh <tag> [pytest-selector]
+# One GPU-box cycle (run through gpurun from the repo root):  bash tools/gpu_cycle.sh <tag> [steps...]
+# steps: bf16tests alltests gemmbench bench benchfull stress   (default: alltests bench)
+# A step that fails its assertions does not stop the cycle; a step that TIMES OUT or is killed does (nothing further touches the GPU).
 set -o pipefail
-TAG=${1:-cycle}
-SEL=${2:-tests}
+TAG=${1:-cycle}; shift
+STEPS=${@:-alltests bench}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/$TAG /tmp/prof_$TAG
-timeout -k 10 600 python -m pytest $SEL -q -m gpu -x > gpurun_out/$TAG/tests.log 2>&1
-echo "tests rc=$?"; tail -4 gpurun_out/$TAG/tests.log
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-bert > gpurun_out/$TAG/bench_prof.json 2> gpurun_out/$TAG/bench_prof.err
-echo "prof rc=$?"
-for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f gpurun_out/$TAG/kernel_stats.csv; done
-python3 - <<PY
-import csv
-rows=list(csv.DictReader(open("gpurun_out/$TAG/kernel_stats.csv")))
-for r in rows[:14]:
-    print(f"{r['Name'][:70]:70s} calls={r['Calls']:>7s} avg_us={float(r['AverageNs'])/1e3:8.2f} pct={r['Percentage']}")
-PY
-python3 -c "
-import json;d=json.load(open('gpurun_out/$TAG/bench_prof.json'));print('tok/s',round(d['value']),'ms/gen',round(d['ms_per_step'],1),'nodes',d['graph']['graph_nodes'],'attn GB/s',d['roofline'] and round(d['roofline']['achieved']), d['roofline'] and d['roofline']['step_breakdown_ms'])"
+run() {  # run <name> <seconds> <cmd...>
+  local name=$1 secs=$2; shift 2
+  echo "== $name: $*" | tee -a $OUT/cycle.log
+  timeout -k 10 $secs "$@" > $OUT/$name.log 2>&1
+  local rc=$?
+  echo "$name rc=$rc" | tee -a $OUT/cycle.log
+  tail -n 6 $OUT/$name.log
+  [ $rc -lt 124 ]
+}
+for s in $STEPS; do
+  case $s in
+    bf16tests) run bf16tests 900 python3 -m pytest tests/test_gpu_bf16.py -x -q -m gpu -s || exit 1 ;;
+    alltests)  run alltests 1100 python3 -m pytest tests -x -q -m gpu || exit 1 ;;
+    gemmbench) run gemmbench 300 python3 tools/gemm_bf16_bench.py || exit 1 ;;
+    stress)    run stress 400 python3 tools/gemm_bf16_stress.py 200 noise || exit 1 ;;
+    bench)     run bench 400 python3 bench.py --steps 2 --warmup 1 --no-cpu || exit 1 ;;
+    benchfull) run benchfull 600 python3 bench.py || exit 1 ;;
+    bertprof)  rm -rf /tmp/bp_$TAG; run bertprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp_$TAG -- python3 tools/bert_prof.py bf16 || exit 1
+               f=$(find /tmp/bp_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bert_bf16_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
+    benchprof) rm -rf /tmp/bn_$TAG; run benchprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bn_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra || exit 1
+               f=$(find /tmp/bn_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
+    bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
+    *) echo "unknown step $s"; exit 2 ;;
+  esac
+done
