@@ -208,13 +208,14 @@ def whole_step_bytes(geo, B, Tp, n_steps, e_w, e_kv):
     return sum(p_step * e_w + B * NL * 2 * C_ * e_kv * (Tp + i + 1 + 1) for i in range(n_steps))
 
 
-def prefill_extra(arena, device, B=64, T=1024, reps=5):
+def prefill_extra(arena, device, B=64, T=1024, reps=5, dtype="f32"):
     """north_star: ">= 50 % MFMA-roofline on prefill".  Decoder-S [64, 1024] non-causal prefill with the logits of every
     position (api_cache.py:87-106 returns them; SURVEY §8d: 3.86 TFLOP = dense 3.03 + attention 0.82)."""
     from mgea import synth
     from mgea.decoder import DecoderEngine
-    eng = DecoderEngine(None, n_head=N_HEAD, max_batch=B, max_ctx=T, device=device, geometry=DEC, arena=arena)
+    eng = DecoderEngine(None, n_head=N_HEAD, max_batch=B, max_ctx=T, device=device, geometry=DEC, arena=arena, dtype=dtype)
     ids = torch.from_numpy(synth.integers(1, "prefill", (B, T), 0, DEC["vocab"])).to(device=device, dtype=torch.int32)
+    peak = 157.3 if dtype == "f32" else 2500.0
     out = {}
     C_, NL, V = DEC["d_model"], DEC["n_layer"], DEC["vocab"]
     for name, want_logits in (("with_logits", True), ("cache_fill_only", False)):
@@ -232,14 +233,17 @@ def prefill_extra(arena, device, B=64, T=1024, reps=5):
         dt = sorted(times)[len(times) // 2]
         flops = 2 * B * T * (NL * 12 * C_ * C_ + (V * C_ if want_logits else 0)) + 4 * B * T * T * C_ * NL
         out[name] = dict(ms=dt * 1e3, tokens_per_sec=B * T / dt, tflops=flops / dt / 1e12, algorithmic_tflop=flops / 1e12,
-                         frac_of_f32_mfma_peak=flops / dt / 1e12 / 157.3, ms_each=[round(t * 1e3, 2) for t in times])
+                         frac_of_mfma_peak=flops / dt / 1e12 / peak, ms_each=[round(t * 1e3, 2) for t in times])
+    st = eng.stats()
     eng.close()
     w = out["with_logits"]
-    return dict(metric="decoder_prefill_tokens_per_sec", value=w["tokens_per_sec"], unit="tokens/s", ms=w["ms"], dtype="f32",
+    note = ("exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the f32 matrix peak is 157.3 TFLOP/s, 1/16 of the bf16 one" if dtype == "f32" else
+            "fp16 perf mode: v_mfma_f32_16x16x32_f16 GEMMs (persistent 256 x 256 kernel, LayerNorm folded), fp16 flash attention, fp32-output "
+            "head; against the dense f16 MFMA peak")
+    return dict(metric="decoder_prefill_tokens_per_sec", value=w["tokens_per_sec"], unit="tokens/s", ms=w["ms"], dtype=dtype,
                 workload=f"Decoder-S non-causal prefill, ids [{B}, {T}], logits for every position, empty cache, random weights",
-                roofline=dict(bound="mfma", achieved=w["tflops"], peak=157.3, unit="TFLOP/s", frac=w["frac_of_f32_mfma_peak"], traffic=None,
-                              note="exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the f32 matrix peak is 157.3 TFLOP/s, 1/16 of the bf16 one"),
-                cache_fill_only=out["cache_fill_only"])
+                roofline=dict(bound="mfma", achieved=w["tflops"], peak=peak, unit="TFLOP/s", frac=w["frac_of_mfma_peak"], traffic=None, note=note),
+                cache_fill_only=out["cache_fill_only"], prefill16_forwards=st.get("prefill16_forwards", 0))
 
 
 DEC_L = dict(vocab=8324, seq_len=2048, d_model=768, n_layer=12, d_ff=3072)   # BASELINE configs[4]; 12 heads x 64
@@ -442,9 +446,10 @@ def main():
             eng.close()
             eng = None
             extra["decoder_prefill"] = prefill_extra(arena, device)
+            extra["decoder_prefill_f16"] = prefill_extra(arena, device, dtype="f16")
         if not args.no_bert and not args.no_extra and world == 1:
             extra["distilbert"] = bert_extra(device, max(2, args.steps), 1, not args.no_cpu, keep_logits=True)
-            extra["distilbert_bf16"] = bert_extra(device, max(3, args.steps), 2, False, dtype="bf16", ref_logits=extra["distilbert"].pop("_logits"))
+            extra["distilbert_bf16"] = bert_extra(device, max(10, args.steps), 2, False, dtype="bf16", ref_logits=extra["distilbert"].pop("_logits"))
         if world == 1 and not args.no_extra:
             # BASELINE configs[4] as written: fp16 storage, top-p 0.9, 2048 tokens, captured step graph (one GPU's share)
             top_p = dict(temperature=1.0, top_k=None, top_p=0.9, seed=1)

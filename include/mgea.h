@@ -149,7 +149,8 @@ int mgea_decoder_profile_read(mgea_decoder* h, double* ms_by_class, int64_t* lau
                               int32_t n_classes);
 
 /* out[0] kernels in the step graph last used, [1] graph replays of the last generate(), [2] graph
- * captures + instantiations over the handle's lifetime, [4] graphs cached now; others 0. */
+ * captures + instantiations over the handle's lifetime, [4] graphs cached now, [5] forwards that ran on the f16 matrix-core
+ * prefill path (MGEA_DTYPE_F16 engines, empty cache, batch * T big enough: csrc/decoder.hip run_prefill16); others 0. */
 int mgea_decoder_stats(mgea_decoder* h, int64_t* out /* [8] */);
 
 /* Token ids outside [0, vocab) make nn.Embedding raise IndexError in the reference (api_cache.py:99).

@@ -25,18 +25,21 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+template <typename T>
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const float4 v = ld4(src + i);
-        bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-        *reinterpret_cast<bf16x4*>(dst + i) = o;
+        t4 o = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+        *reinterpret_cast<t4*>(dst + i) = o;
     } else {
-        for (int64_t j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+        for (int64_t j = i; j < n; ++j) dst[j] = (T)src[j];
     }
 }
-int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st, int f16) {
+    if (f16) hipLaunchKernelGGL(f32_to_bf16_kernel<_Float16>, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, src, (_Float16*)dst, n);
+    else     hipLaunchKernelGGL(f32_to_bf16_kernel<bf16_t>, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, src, (bf16_t*)dst, n);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -46,7 +49,8 @@ enum { BEPI_BIAS = 0, BEPI_BIAS_GELU = 1, BEPI_BIAS_RES = 2,
        // LayerNorm folded around the GEMMs (persistent 256 x 256 kernel only; see BfEpiLn in common.h):
        BEPI_LNFOLD = 3,        // out = rstd_row (A W'^T - mean_row c1) + c2         (A = raw rows, W' = W diag(gamma), c2 in the bias slot)
        BEPI_LNFOLD_GELU = 4,   // ... then GELU
-       BEPI_RES_LN = 5 };      // out = A W^T + bias + LN(res rows) (LayerNorm of the residual applied on the way in), + row statistics of out
+       BEPI_RES_LN = 5,        // out = A W^T + bias + LN(res rows) (LayerNorm of the residual applied on the way in), + row statistics of out
+       BEPI_BIAS_F32 = 6 };    // out = A W^T + bias written as fp32 [M, ldc floats] (the decoder's LM head: N = vocab need only be a multiple of 4)
 
 // erf-GELU for bf16 outputs with ONE transcendental.  With a = |x|: gelu(x) = max(x, 0) - 0.5 a erfc(a / sqrt 2), and
 // erfc(a / sqrt 2) = 2^q(a) where q = log2(erfcx) - (a^2 / 2) log2 e is smooth: a degree-5 polynomial (weighted least squares on
@@ -369,6 +373,23 @@ __device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned voff
 
 typedef unsigned long long u64x1;
 
+// The two 16-bit storage types of the perf modes (bf16: DistilBERT, MGEA_DTYPE_BF16; fp16: the decoder's big-batch prefill,
+// MGEA_DTYPE_F16) behind one set of kernels: vector types, the 16 x 16 x 32 MFMA, and a packed pair (one dword) <-> two fp32.
+template <typename T> struct X16;
+template <> struct X16<__bf16> {
+    typedef bf16x8 v8; typedef bf16x4 v4; typedef bf16x2 v2;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x2 unpack(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+};
+template <> struct X16<_Float16> {
+    typedef h16x8 v8; typedef h16x4 v4; typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x2 unpack(unsigned u) {
+        const v2 h = __builtin_bit_cast(v2, u);
+        return (f32x2){(float)h[0], (float)h[1]};
+    }
+};
+
 // Sum over the 32 lanes of a half wave (lanes 32 h .. 32 h + 31), result in all of them: four DPP row rotations (VALU speed) give
 // the 16-lane sums, one ds_bpermute adds the neighbouring row.  (Five __shfl_xor steps = five trips through the LDS pipeline per
 // value: 160 of them per tile made the statistics cost more than the LayerNorm kernel they replace.)
@@ -379,11 +400,14 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v + __shfl_xor(v, 16, 64);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
-                                                          const float* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                          bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
+template <int EPI, typename T>
+__global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, const T* __restrict__ res,
+                                                          T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
                                                           int tail_mode, BfEpiLn ln) {
+    typedef typename X16<T>::v8 v8;
+    typedef typename X16<T>::v4 v4;
+    typedef typename X16<T>::v2 v2;
     constexpr int BM = 256, BN = 256;
     constexpr bool LNF = EPI == BEPI_LNFOLD || EPI == BEPI_LNFOLD_GELU;
     constexpr bool RESV = EPI == BEPI_BIAS_RES || EPI == BEPI_RES_LN;
@@ -439,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
     // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
     // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
-    const bf16_t* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
+    const T* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int t, int md) {                    // md != 0: the 128 rows of that half sit in rows 0..127 of the A stage
         m0 = (t / tiles_n) * BM + (md == 2 ? 128 : 0); n0 = (t % tiles_n) * BN;
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
 
-        bf16x8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
+        v8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
         if (!halfu) {
         for (int u = 0; u < nkt; ++u) {
             const float4* sb = lds + (u & 1) * STAGE;
@@ -539,8 +563,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                            if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
-                            else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                            if (p == 0) bf0[n][ks] = *reinterpret_cast<const v8*>(&v);
+                            else        bf1[n][ks] = *reinterpret_cast<const v8*>(&v);
                         }
                 }
                 if (p == 0 || p == 2) {      // A fragments of the 64-row half i = p / 2
@@ -549,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             const float4 v = sa[(((p >> 1) * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                            af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                            af[m][ks] = *reinterpret_cast<const v8*>(&v);
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -573,8 +597,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
                             const int i = p >> 1, j = (p == 1 || p == 2) ? 1 : 0;
-                            const bf16x8 wv = j ? bf1[n][ks] : bf0[n][ks];
-                            acc[j * 2 + n][i * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[j * 2 + n][i * 4 + m], 0, 0, 0);
+                            const v8 wv = j ? bf1[n][ks] : bf0[n][ks];
+                            acc[j * 2 + n][i * 4 + m] = X16<T>::mfma(wv, af[m][ks], acc[j * 2 + n][i * 4 + m]);
                         }
                 __builtin_amdgcn_s_setprio(0);
                 if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
@@ -599,8 +623,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const float4 v = sw[((p * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                        if (p == 0) bf0[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
-                        else        bf1[n][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                        if (p == 0) bf0[n][ks] = *reinterpret_cast<const v8*>(&v);
+                        else        bf1[n][ks] = *reinterpret_cast<const v8*>(&v);
                     }
                 if (p == 0) {                    // A fragments: the wave's 64 rows
 #pragma unroll
@@ -608,7 +632,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             const float4 v = sa[(m * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
-                            af[m][ks] = *reinterpret_cast<const bf16x8*>(&v);
+                            af[m][ks] = *reinterpret_cast<const v8*>(&v);
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -629,8 +653,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
-                            const bf16x8 wv = p ? bf1[n][ks] : bf0[n][ks];
-                            acc[p * 2 + n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[m][ks], acc[p * 2 + n][m], 0, 0, 0);
+                            const v8 wv = p ? bf1[n][ks] : bf0[n][ks];
+                            acc[p * 2 + n][m] = X16<T>::mfma(wv, af[m][ks], acc[p * 2 + n][m]);
                         }
                 __builtin_amdgcn_s_setprio(0);
                 if (p == 1 && wm == 0) {     // ... the early group at the end of its C(2u+1): the same interval
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
         // through a load round trip in the middle of the chip-wide store burst (FC2: 34 of 168 us were residual loads + stores).
         // RES_LN: the residual is LayerNorm(res row) -- the raw row comes with its (mean, rstd), gamma / beta of this thread's 8
         // columns are loaded once per tile (a thread keeps its 16-byte chunk index through all passes).
-        bf16x8 rnext[4];
+        v8 rnext[4];
         float2 snext[4];
         const int my_col = cn0 + (tid & 31) * 8;
         // (unconditional loads: a load behind a run-time branch makes hipcc wait vmcnt(0) right after it, which put a full round trip
@@ -702,11 +726,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                 const int lrow = (prow >> 5) * wrows + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 int row = cm0 + lrow, col = cn0 + ch * 8;
                 row = row < M ? row : M - 1; col = col < N ? col : 0;         // clamped: loaded, not used
-                rnext[i] = *reinterpret_cast<const bf16x8*>(res + (int64_t)row * ldc + col);
+                rnext[i] = *reinterpret_cast<const v8*>(res + (int64_t)row * ldc + col);
                 if (EPI == BEPI_RES_LN) snext[i] = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
             }
         };
         if (RESV) load_res(0);
+        if constexpr (EPI != BEPI_BIAS_F32) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= kpass) break;                            // workgroup-uniform
@@ -726,14 +751,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                         const f32x2 g0 = gelu_fast2((f32x2){v.x, v.y}), g1 = gelu_fast2((f32x2){v.z, v.w});
                         v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     }
-                    bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+                    v4 o = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
                     const int ch = (lcol >> 3) ^ (prow & 31);
-                    *reinterpret_cast<bf16x4*>(sC + prow * 512 + ch * 16 + (lcol & 7) * 2) = o;
+                    *reinterpret_cast<v4*>(sC + prow * 512 + ch * 16 + (lcol & 7) * 2) = o;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            bf16x8 rcur[4];
+            v8 rcur[4];
             float2 scur[4];
             if (RESV) {
 #pragma unroll
@@ -759,14 +784,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                     const f32x2 bet2[4] = {{bet0.x, bet0.y}, {bet0.z, bet0.w}, {bet1.x, bet1.y}, {bet1.z, bet1.w}};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        f32x2 x = {__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)};
-                        f32x2 r = {__uint_as_float(rw[q] << 16), __uint_as_float(rw[q] & 0xffff0000u)};
+                        f32x2 x = X16<T>::unpack(vw[q]);
+                        f32x2 r = X16<T>::unpack(rw[q]);
                         if (EPI == BEPI_RES_LN) {
                             r = __builtin_elementwise_fma(r, (f32x2){ra, ra}, (f32x2){rb, rb});
                             r = __builtin_elementwise_fma(r, gam2[q], bet2[q]);
                         }
                         x = x + r;
-                        const bf16x2 o = {(bf16_t)x[0], (bf16_t)x[1]};
+                        const v2 o = {(T)x[0], (T)x[1]};
                         vw[q] = __builtin_bit_cast(unsigned, o);
                     }
                 }
@@ -779,12 +804,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
                     // (rows beyond M compute garbage that is never stored)
                     f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) s1p += (f32x2){__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)};
+                    for (int q = 0; q < 4; ++q) s1p += X16<T>::unpack(vw[q]);
                     const float s1 = half_wave_sum(s1p[0] + s1p[1]);
                     const float tmean = s1 * (1.0f / 256.0f);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x2 d = (f32x2){__uint_as_float(vw[q] << 16), __uint_as_float(vw[q] & 0xffff0000u)} - (f32x2){tmean, tmean};
+                        const f32x2 d = X16<T>::unpack(vw[q]) - (f32x2){tmean, tmean};
                         s2p = __builtin_elementwise_fma(d, d, s2p);
                     }
                     const float s2 = half_wave_sum(s2p[0] + s2p[1]);
@@ -795,17 +820,46 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const bf16_t* __restr
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                     // the C stage is rewritten by the next pass
         }
+        } else {
+            // fp32 rows: 8 passes (4 for a half unit) of 32 rows -- m-tile k of both wave rows -- through the same 32 KB C stage:
+            // 32 rows x 1 KB, the 16-byte chunk XOR-swizzled by the row (the 16 rows a ds_write_b128 touches would share their
+            // banks: the row pitch is a multiple of the 256-byte bank row), streamed out as whole rows, 16 bytes per lane.
+            float* Cf = reinterpret_cast<float*>(C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < 2 * kpass) {                              // workgroup-uniform (no `break`: hipcc then leaves the loop rolled and acc[n][k] goes to scratch)
+                const int prow = wm * 16 + c;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int lcol = wn * 64 + n * 16 + 4 * g;
+                    const float4 v = add4(make_float4(acc[n][k][0], acc[n][k][1], acc[n][k][2], acc[n][k][3]), bv[n]);
+                    *reinterpret_cast<float4*>(sC + prow * 1024 + (((lcol >> 2) ^ (prow & 15)) * 16)) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                      // 32 rows x 64 chunks = 2048 chunks / 512 threads
+                    const int id = tid + i * 512, pr = id >> 6, ch = id & 63;
+                    const int row = cm0 + (pr >> 4) * wrows + k * 16 + (pr & 15), col = cn0 + ch * 4;
+                    const float4 v = *reinterpret_cast<const float4*>(sC + pr * 1024 + ((ch ^ (pr & 15)) * 16));
+                    if (row < M && col < N) *reinterpret_cast<float4*>(Cf + (int64_t)row * ldc + col) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                     // the C stage is rewritten by the next pass
+                }
+            }
+        }
     }
 }
 
-template <int EPI>
-static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c, int ldc, int M,
+template <int EPI, typename T = bf16_t>
+static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
                      int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
     const int shmem = 2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     DeviceInfo di;
     MGEA_TRY(device_info(&di));
     static uint64_t attr_done = 0;                      // per instantiation, one bit per device
-    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI>), shmem, di.dev, &attr_done));
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI, T>), shmem, di.dev, &attr_done));
     const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
     const int n_cu = di.n_cu / 8 * 8;
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
@@ -816,7 +870,7 @@ static int launch_ph(const bf16_t* a, int lda, const bf16_t* w, int ldw, const f
         info->kernel = 2;
         info->half_tiles = (tail != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
     }
-    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
                        tail, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
@@ -865,10 +919,34 @@ static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, 
 
 bool gemm_bf16_is_persistent(int M, int N, int K) { return pick_bf16_kernel(M, N, K, 8) == 2; }
 
+// fp16 operands (the decoder's big-batch prefill): the persistent kernel only, epilogues 3 / 4 / 5 and the fp32-output head (6)
+static int launch_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C, int ldc, int M, int N,
+                           int K, int epi, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp) {
+    typedef _Float16 H;
+    const H *a = (const H*)A, *w = (const H*)W, *r = (const H*)res;
+    H* c = (H*)C;
+    MGEA_REQUIRE(M >= 512 && N >= 256 && (int64_t)ceil_div(M, 256) * ceil_div(N, 256) >= 8, MGEA_EINVAL,
+                 "fp16 gemm: M=%d N=%d below what the persistent kernel takes", M, N);
+    if (epi == BEPI_BIAS_F32) {
+        MGEA_REQUIRE(bias && N % 4 == 0 && ldc % 4 == 0, MGEA_EINVAL, "fp16 gemm: fp32-output epilogue needs a bias and N, ldc multiples of 4");
+        return launch_ph<BEPI_BIAS_F32, H>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    }
+    MGEA_REQUIRE(epi >= BEPI_LNFOLD && epi <= BEPI_RES_LN && lnp && bias && N % 256 == 0 && ldc % 8 == 0, MGEA_EINVAL,
+                 "fp16 gemm: epilogue %d / shape not built (3, 4, 5 with N %% 256 == 0, or 6)", epi);
+    if (epi == BEPI_RES_LN) {
+        MGEA_REQUIRE(res && lnp->rowstat && lnp->ln_g && lnp->ln_b, MGEA_EINVAL, "fp16 gemm: RES_LN without residual / row statistics / gamma / beta");
+        return launch_ph<BEPI_RES_LN, H>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    }
+    MGEA_REQUIRE(lnp->rowstat && lnp->c1, MGEA_EINVAL, "fp16 gemm: LNFOLD without row statistics / c1");
+    if (epi == BEPI_LNFOLD) return launch_ph<BEPI_LNFOLD, H>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    return launch_ph<BEPI_LNFOLD_GELU, H>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+}
+
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp) {
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp, int f16) {
     MGEA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
                  MGEA_EINVAL, "bf16 gemm: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
+    if (f16) return launch_gemm_f16(A, lda, W, ldw, bias, res, C, ldc, M, N, K, epi, st, info, lnp);
     if (epi >= BEPI_LNFOLD) {   // LayerNorm folded around the GEMM: the persistent kernel only
         MGEA_REQUIRE(epi <= BEPI_RES_LN && lnp && bias, MGEA_EINVAL, "bf16 gemm: epilogue %d needs its LayerNorm operands and a bias / c2 vector", epi);
         MGEA_REQUIRE(gemm_bf16_is_persistent(M, N, K) && ldc % 8 == 0 && N % 256 == 0, MGEA_EINVAL,
@@ -938,15 +1016,16 @@ int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int 
 
 // W' = bf16(W diag(gamma)), c1[n] = sum_k W'[n, k] (of the ROUNDED folded weights: the epilogue subtracts exactly what the MFMAs
 // added), c2[n] = b[n] + sum_k W[n, k] beta[k].  One workgroup per output row n.
+template <typename T>
 __global__ __launch_bounds__(256) void fold_ln_weights_bf16_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, const float* __restrict__ b,
-                                                                  bf16_t* __restrict__ Wf, float* __restrict__ c1,
+                                                                  T* __restrict__ Wf, float* __restrict__ c1,
                                                                   float* __restrict__ c2, int K) {
     const int64_t n = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float w = W[n * K + k];
-        const bf16_t wf = (bf16_t)(w * gamma[k]);
+        const T wf = (T)(w * gamma[k]);
         Wf[n * K + k] = wf;
         s1 += (float)wf;
         s2 = fmaf(w, beta[k], s2);
@@ -961,8 +1040,9 @@ __global__ __launch_bounds__(256) void fold_ln_weights_bf16_kernel(const float* 
     }
 }
 int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float* beta, const float* b, void* Wf, float* c1, float* c2,
-                                int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(fold_ln_weights_bf16_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, b, (bf16_t*)Wf, c1, c2, K);
+                                int N, int K, hipStream_t st, int f16) {
+    if (f16) hipLaunchKernelGGL(fold_ln_weights_bf16_kernel<_Float16>, dim3(N), dim3(256), 0, st, W, gamma, beta, b, (_Float16*)Wf, c1, c2, K);
+    else     hipLaunchKernelGGL(fold_ln_weights_bf16_kernel<bf16_t>, dim3(N), dim3(256), 0, st, W, gamma, beta, b, (bf16_t*)Wf, c1, c2, K);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -1156,9 +1236,13 @@ __device__ __forceinline__ float quad_max(float x) {
 // S^T = K Q^T keeps a query's scores lane-local (lane = query, registers = keys 16 kt + 4 g + r); the k index of the P V product is
 // permuted to match (k = 8 g + j  <->  key 32 p + 16 (j >> 2) + 4 g + (j & 3)), so P goes from accumulator to operand in registers.
 // The output tile goes through the (then free) K image so that every store instruction writes complete 128-byte rows.
+template <typename E>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ mask, bf16_t* __restrict__ out, int T, int H,
+void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mask, E* __restrict__ out, int T, int H,
                       int n_items, int nqb, float scale) {
+    typedef typename X16<E>::v8 bf16x8;   // (the names below were written for bf16; E may be _Float16)
+    typedef typename X16<E>::v4 bf16x4;
+    typedef E bf16_t;
     constexpr int DH = 64, KB = 128;
     constexpr int STAGE = 2048;                                   // 16-byte chunks: K image, then V image
     extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE], then [2][2] 64-bit validity words
@@ -1293,8 +1377,8 @@ void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict_
                     const int key = t0 + kt * 16 + c;
                     const float4 kv = sK[key * 8 + ((ks * 4 + g) ^ (key & 7))];
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&kv);
-                    sc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], sc[0][kt], 0, 0, 0);
-                    sc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], sc[1][kt], 0, 0, 0);
+                    sc[0][kt] = X16<E>::mfma(kf, qf[0][ks], sc[0][kt]);
+                    sc[1][kt] = X16<E>::mfma(kf, qf[1][ks], sc[1][kt]);
                 }
             float tmax[2];
 #pragma unroll
@@ -1346,8 +1430,8 @@ void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict_
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                         // row sums of the bf16 P the P V product actually uses
-                lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][p], lacc[0], 0, 0, 0);
-                lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][p], lacc[1], 0, 0, 0);
+                lacc[0] = X16<E>::mfma(ones, pf[0][p], lacc[0]);
+                lacc[1] = X16<E>::mfma(ones, pf[1][p], lacc[1]);
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -1358,8 +1442,8 @@ void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict_
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 16 * 64));
                     union { s16x4 s[2]; bf16x8 v; } u;
                     u.s[0] = lo; u.s[1] = hi;
-                    oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[0][p], oacc[0][dt], 0, 0, 0);
-                    oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[1][p], oacc[1][dt], 0, 0, 0);
+                    oacc[0][dt] = X16<E>::mfma(u.v, pf[0][p], oacc[0][dt]);
+                    oacc[1][dt] = X16<E>::mfma(u.v, pf[1][p], oacc[1][dt]);
                 }
         }
 
@@ -1400,7 +1484,7 @@ void attn_bf16_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict_
 #undef MGEA_FLUSH_OUT
 }
 
-int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st) {
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16) {
     MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
     const int nqb = ceil_div(T, 128);
@@ -1412,10 +1496,112 @@ int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int
     const int n_cu = di.n_cu;
     const int shmem = 2 * 2048 * 16 + 64;
     static uint64_t attr_done = 0;
-    MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel, shmem, di.dev, &attr_done));
+    static uint64_t attr_done_h = 0;
+    if (f16) MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<_Float16>, shmem, di.dev, &attr_done_h));
+    else     MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<bf16_t>, shmem, di.dev, &attr_done));
     const int grid = (int)(n_items < 2 * n_cu ? n_items : 2 * n_cu);
-    hipLaunchKernelGGL(attn_bf16_kernel, dim3(grid), dim3(256), shmem, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
-                       (int)n_items, nqb, 1.0f / sqrtf((float)dh));
+    if (f16)
+        hipLaunchKernelGGL(attn_bf16_kernel<_Float16>, dim3(grid), dim3(256), shmem, st, (const _Float16*)qkv, mask, (_Float16*)out, T, H,
+                           (int)n_items, nqb, 1.0f / sqrtf((float)dh));
+    else
+        hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, dim3(grid), dim3(256), shmem, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
+                           (int)n_items, nqb, 1.0f / sqrtf((float)dh));
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fp16 big-batch prefill of the decoder (MGEA_DTYPE_F16, decoder.hip: run_prefill16): the pre-LN GPT block on the kernels above with
+// _Float16 operands.  Three small kernels around them:
+// x[m] = f16(tok_emb[ids[m]] + pos_emb[pos]) and the (mean, rstd) of the ROUNDED row (what the folded-LayerNorm GEMM consumes);
+// rows with t >= lens[b] are zero rows with the identity statistics (0, 1).  One wave per row.
+__global__ __launch_bounds__(256) void dec_embed_f16_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
+                                                           const int32_t* __restrict__ ctx_len, const float* __restrict__ tok_emb,
+                                                           const float* __restrict__ pos_emb, _Float16* __restrict__ x,
+                                                           float* __restrict__ rowstat, float eps, int M, int T, int C, int vocab,
+                                                           int pos_rows, int absolute_pos, int32_t* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = (int)(m / T), t = (int)(m % T);
+    const bool real = lens ? (t < lens[b]) : true;
+    int id = ids[m];
+    if (real && (id < 0 || id >= vocab) && err_flag && lane == 0) atomicOr(err_flag, 1);
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pos = t + ((absolute_pos && ctx_len) ? ctx_len[b] : 0);
+    pos = pos < pos_rows ? pos : pos_rows - 1;
+    const int nf4 = C >> 2;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = lane + i * 64;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nf4 && real) {
+            const float4 e = add4(ld4(tok_emb + (int64_t)id * C + f * 4), ld4(pos_emb + (int64_t)pos * C + f * 4));
+            const h16x4 o = {(_Float16)e.x, (_Float16)e.y, (_Float16)e.z, (_Float16)e.w};
+            v[i] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        }
+        if (f < nf4) {
+            const h16x4 o = {(_Float16)v[i].x, (_Float16)v[i].y, (_Float16)v[i].z, (_Float16)v[i].w};
+            *reinterpret_cast<h16x4*>(x + m * C + f * 4) = o;
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + i * 64 < nf4) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    const float var = wave_sum(q) / (float)C;
+    if (lane == 0) *reinterpret_cast<float2*>(rowstat + m * 2) = real ? make_float2(mean, 1.0f / sqrtf(var + eps)) : make_float2(0.f, 1.f);
+}
+int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,
+                         void* x, float* rowstat, float eps, int B, int T, int C, int vocab, int pos_rows, int absolute_pos,
+                         int32_t* err_flag, hipStream_t st) {
+    MGEA_REQUIRE(C % 4 == 0 && C <= 2048, MGEA_EINVAL, "fp16 embed: d_model=%d must be a multiple of 4 and <= 2048", C);
+    hipLaunchKernelGGL(dec_embed_f16_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb,
+                       (_Float16*)x, rowstat, eps, B * T, T, C, vocab, pos_rows, absolute_pos, err_flag);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
+// K | V columns of the fp16 qkv rows [M, 3C] -> the fp16 KV pages of `layer` (common.h: K [dh/8][64 tokens][8], V [64 tokens][dh]):
+// one thread per 16-byte group, real tokens only, position ctx_len[b] + t.  mask_out (or nullptr) receives the [B, T] key validity the
+// dense attention wants for ragged prompts.
+__global__ __launch_bounds__(256) void kv_scatter_f16_kernel(const _Float16* __restrict__ qkv, KvPool pool, int layer,
+                                                            const int32_t* __restrict__ page_table, int max_pages,
+                                                            const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ lens,
+                                                            int32_t* __restrict__ mask_out, int64_t n_groups, int T, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_groups) return;
+    const int gpr = (2 * C) >> 3;                       // 16-byte groups of K | V per row
+    const int64_t m = gid / gpr;
+    const int gi = (int)(gid - m * gpr);
+    const int b = (int)(m / T), t = (int)(m % T);
+    const bool real = lens ? (t < lens[b]) : true;
+    if (mask_out && gi == 0) mask_out[m] = real ? 1 : 0;
+    if (!real) return;
+    const int pos = ctx_len[b] + t;
+    const int page = pos >> 6, slot = pos & 63;
+    if (page >= max_pages) return;
+    const int phys = page_table[b * max_pages + page];
+    const int n = gi * 8;                                // column inside K | V
+    const int isv = n >= C, nn = n - (isv ? C : 0), head = nn / pool.dh, d = nn % pool.dh;
+    const float4 raw = *reinterpret_cast<const float4*>(qkv + m * 3 * C + C + n);
+    const int64_t pe = pool.page_elems();
+    _Float16* pg = static_cast<_Float16*>(pool.base) + layer * pool.layer_stride + ((int64_t)(phys * 2 + isv) * pool.H + head) * pe;
+    *reinterpret_cast<float4*>(pg + (isv ? slot * pool.dh + d : ((d >> 3) * MGEA_KV_PAGE_TOKENS + slot) * 8)) = raw;
+}
+int launch_kv_scatter_f16(const void* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages, const int32_t* ctx_len,
+                          const int32_t* lens, int32_t* mask_out, int B, int T, int C, hipStream_t st) {
+    MGEA_REQUIRE(pool.f16 && pool.dh % 8 == 0 && C % 8 == 0, MGEA_EINVAL, "fp16 KV scatter needs fp16 pages and head_dim %% 8 == 0");
+    const int64_t n_groups = (int64_t)B * T * ((2 * C) >> 3);
+    hipLaunchKernelGGL(kv_scatter_f16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, (const _Float16*)qkv, pool, layer,
+                       page_table, max_pages, ctx_len, lens, mask_out, n_groups, T, C);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

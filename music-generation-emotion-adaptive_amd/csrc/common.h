@@ -45,6 +45,8 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BF16_GEMM_TAIL,       // persistent kernel, tiles left after the full rounds: 0 whole tiles, 1 two 128-row halves, 2 = 1 + staggered order
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
+       TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
+                                  // fills the chip (default), 2 whenever the kernels accept the shape (tests)
        TUNE_COUNT };
 int tune(int key);
 
@@ -213,7 +215,7 @@ int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int
                       hipStream_t st);
 
 // ---- bf16 perf-mode kernels (bf16.hip); bf16 buffers travel as void* ---------------------------
-int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st);
+int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st, int f16 = 0);   // f16: _Float16 instead of bf16
 // C = epi(A @ W^T + bias): epi 0 bias, 1 bias + GELU, 2 bias + residual(res, ld = ldc)
 // LayerNorm folded around the bf16 GEMMs (bf16.hip, epilogues 3-5 of launch_gemm_bf16; persistent 256 x 256 kernel only).
 //   epi 3 / 4 (LNFOLD / +GELU): A = RAW rows, W = W diag(gamma) in bf16, c1[n] = sum_k W'[n, k], bias slot = c2 = b + W beta;
@@ -228,19 +230,27 @@ struct BfEpiLn { const float* rowstat; const float* c1; const float* ln_g; const
 // kernel cuts the tiles left over after its full rounds into two 128-row halves (bf16.hip, "HALF-TILE TAIL").
 struct GemmBf16Info { int kernel; int half_tiles; };
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
-                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info = nullptr, const BfEpiLn* ln = nullptr);
+                     int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info = nullptr, const BfEpiLn* ln = nullptr,
+                     int f16 = 0);   // f16 != 0: _Float16 operands / outputs (persistent kernel, epilogues 3 / 4 / 5, and 6 = fp32 output)
 // true when launch_gemm_bf16 would run this shape on the persistent 256 x 256 kernel (the only one with epilogues 3-5)
 bool gemm_bf16_is_persistent(int M, int N, int K);
 int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st);
 int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float* beta, const float* b, void* Wf, float* c1, float* c2,
-                                int N, int K, hipStream_t st);
+                                int N, int K, hipStream_t st, int f16 = 0);
 int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* g, const float* be, float* out, int B, int S, int D,
                               hipStream_t st);
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
                               float eps, void* h, int B, int S, int D, int vocab, hipStream_t st);
 int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
-int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st);
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16 = 0);
+
+// fp16 big-batch prefill of the decoder (bf16.hip): embedding rows as fp16 + their (mean, rstd); K | V of fp16 qkv rows -> fp16 KV pages
+int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,
+                         void* x, float* rowstat, float eps, int B, int T, int C, int vocab, int pos_rows, int absolute_pos,
+                         int32_t* err_flag, hipStream_t st);
+int launch_kv_scatter_f16(const void* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages, const int32_t* ctx_len,
+                          const int32_t* lens, int32_t* mask_out, int B, int T, int C, hipStream_t st);
 
 // ---- fused skinny GEMM (decode step, M <= MGEA_FUSED_MAX_ROWS): gemm_skinny.hip --------------------------------
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };

@@ -136,6 +136,22 @@ struct mgea_decoder {
     const float* fc1_c2(int l) const { return fc1_c1(l) + cfg.d_ff; }
     const float* tw(int layer, int j) const { return wt_at(wt_off[4 * layer + j]); }
     const float* head_tw() const { return wt_at(wt_off[4 * cfg.n_layer]); }
+
+    // MGEA_DTYPE_F16, big-batch prefill on the f16 matrix cores (run_prefill16 below): fp16 activations, row-major fp16 matrices
+    // (in_proj and fc1 with their LayerNorm's gamma folded in), statistics tables.  Allocated at the first such prefill.
+    struct Prefill16 {
+        int64_t rows = 0;
+        void *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *w = nullptr;
+        float *rowstat = nullptr, *stats_part = nullptr, *ident = nullptr, *vec = nullptr;
+        int32_t* mask = nullptr;
+        bool weights_ready = false;
+        std::vector<int64_t> w_off;      // elements: per layer in_proj', out_proj, fc1', fc2; then the head
+    } p16;
+    const char* p16_w(int i) const { return static_cast<const char*>(p16.w) + p16.w_off[i] * 2; }
+    float* p16_vec(int l, int which) const {   // 0 c1(in_proj) 1 c2(in_proj) 2 c1(fc1) 3 c2(fc1)
+        float* base = p16.vec + (int64_t)l * (6 * cfg.d_model + 2 * cfg.d_ff);
+        return which == 0 ? base : which == 1 ? base + 3 * cfg.d_model : which == 2 ? base + 6 * cfg.d_model : base + 6 * cfg.d_model + cfg.d_ff;
+    }
 };
 
 namespace {
@@ -545,6 +561,129 @@ int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_
     return MGEA_OK;
 }
 
+// ---- fp16 engines: prefill of a big batch on the f16 matrix cores --------------------------------------------------------------
+// The exact-fp32 kernels run a [64, 1024] prefill at 0.67 of THEIR peak, which is 1/16 of the f16 MFMA rate.  When the cache is empty
+// and the batch is big enough for the persistent 256 x 256 GEMM (M / 256 * d_model / 256 >= 256 tiles), an fp16 engine runs the GPT
+// block (api_cache.py:51-74, 87-106) on the kernels of the bf16 DistilBERT path with _Float16 operands instead:
+//   x (fp16) + (mean, rstd) per row  ->  per layer:
+//     qkv  = rstd (x W_in'^T - mean c1) + c2            W_in' = f16(W_in diag(ln1 gamma)): LayerNorm folded into the GEMM (epilogue 3)
+//     K | V of the real tokens -> fp16 KV pages;  att = flash attention over qkv (non-causal: the reference has no mask), fp16
+//     x'   = att W_out^T + b + x, + row statistics      (epilogue 5, identity tables: the residual is the raw x)
+//     hid  = gelu(rstd' (x' W_fc1'^T - mean' c1') + c2')  (epilogue 4)
+//     x    = hid W_fc2^T + b + x', + row statistics     (epilogue 5)
+//   logits = x W_head^T + b as fp32                      (epilogue 6, N = vocab)
+// Everything between two GEMM inputs is fp16 (the residual stream too: 11 significant bits, against bf16's 8 in the DistilBERT mode);
+// accumulation, LayerNorm statistics and the softmax are fp32.  W_in' / W_fc1' round gamma * f16(W) once more (the decode path applies
+// gamma to the activations instead): the two paths serve models that differ by one fp16 rounding of those two matrices -- inside
+// the fp16 mode's tolerance (tests/test_gpu_f16.py compares both with the oracle on the rounded matrices).
+void free_p16(mgea_decoder* h) {
+    auto& p = h->p16;
+    void* q[] = {p.x0, p.x1, p.qkv, p.att, p.hid, p.w, p.rowstat, p.stats_part, p.ident, p.vec, p.mask};
+    for (void* v : q)
+        if (v) (void)hipFree(v);
+    p = mgea_decoder::Prefill16();
+}
+
+bool prefill16_ok(const mgea_decoder* h, int64_t M, bool cache_attn, const float* logits_out) {
+    const auto& c = h->cfg;
+    if (!h->f16 || cache_attn || c.block_mode != MGEA_BLOCK_PRELN_GELU || !tune(TUNE_DECODER_PREFILL16)) return false;
+    if (h->dh != 64 || c.d_model % 256 != 0 || c.d_ff % 256 != 0 || c.d_model > 2048) return false;
+    if (logits_out && c.vocab % 4 != 0) return false;
+    // worth it from the size at which the smallest GEMM (N = d_model) fills the chip with 256 x 256 tiles; switch value 2 (tests)
+    // takes every size the kernels accept
+    const int64_t tiles = (M / 256) * (c.d_model / 256);
+    return M >= 512 && M < (1ll << 24) && tiles >= (tune(TUNE_DECODER_PREFILL16) == 2 ? 8 : 256);
+}
+
+int ensure_p16(mgea_decoder* h, int64_t M, hipStream_t st) {
+    auto& p = h->p16;
+    const auto& c = h->cfg;
+    const int64_t C = c.d_model, F = c.d_ff, V = c.vocab, NL = c.n_layer;
+    if (M > p.rows) {
+        MGEA_CHECK_HIP(hipDeviceSynchronize());
+        void** bufs[] = {&p.x0, &p.x1, &p.qkv, &p.att, &p.hid};
+        for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        float** fb[] = {&p.rowstat, &p.stats_part, &p.ident};
+        for (float** b : fb) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        if (p.mask) { (void)hipFree(p.mask); p.mask = nullptr; }
+        const int64_t R = round_up(M, 256);
+        const bool ok = hipMalloc(&p.x0, R * C * 2) == hipSuccess && hipMalloc(&p.x1, R * C * 2) == hipSuccess &&
+                        hipMalloc(&p.qkv, R * 3 * C * 2) == hipSuccess && hipMalloc(&p.att, R * C * 2) == hipSuccess &&
+                        hipMalloc(&p.hid, R * F * 2) == hipSuccess && hipMalloc((void**)&p.rowstat, R * 2 * 4) == hipSuccess &&
+                        hipMalloc((void**)&p.stats_part, R * (C / 256) * 2 * 4) == hipSuccess &&
+                        hipMalloc((void**)&p.ident, (R * 2 + 2 * C) * 4) == hipSuccess && hipMalloc((void**)&p.mask, R * 4) == hipSuccess;
+        if (!ok) {
+            set_error("decoder: out of device memory for the fp16 prefill workspace (%lld tokens)", (long long)M);
+            free_p16(h);
+            return MGEA_ENOMEM;
+        }
+        std::vector<float> idv((size_t)(R * 2 + 2 * C), 0.f);       // (0, 1) per row, then C ones (gamma), then C zeros (beta)
+        for (int64_t r = 0; r < R; ++r) idv[(size_t)r * 2 + 1] = 1.f;
+        for (int64_t d = 0; d < C; ++d) idv[(size_t)(R * 2 + d)] = 1.f;
+        MGEA_CHECK_HIP(hipMemcpy(p.ident, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
+        p.rows = R;
+    }
+    if (!p.weights_ready) {
+        if (!p.w) {
+            p.w_off.clear();
+            int64_t tot = 0;
+            for (int l = 0; l < NL; ++l) {
+                p.w_off.push_back(tot); tot += 3 * C * C;
+                p.w_off.push_back(tot); tot += C * C;
+                p.w_off.push_back(tot); tot += F * C;
+                p.w_off.push_back(tot); tot += C * F;
+            }
+            p.w_off.push_back(tot); tot += round_up(V, 256) * C;     // (rows beyond V are never read: the kernel clamps its row index)
+            if (hipMalloc(&p.w, tot * 2) != hipSuccess || hipMalloc((void**)&p.vec, NL * (6 * C + 2 * F) * 4) != hipSuccess) {
+                set_error("decoder: out of device memory for the fp16 prefill matrices");
+                return MGEA_ENOMEM;
+            }
+        }
+        for (int l = 0; l < NL; ++l) {
+            MGEA_TRY(launch_fold_ln_weights_bf16(h->lw(l, L_INW), h->lw(l, L_LN1W), h->lw(l, L_LN1B), h->lw(l, L_INB), (void*)h->p16_w(4 * l + 0),
+                                                 h->p16_vec(l, 0), h->p16_vec(l, 1), (int)(3 * C), (int)C, st, 1));
+            MGEA_TRY(launch_f32_to_bf16(h->lw(l, L_OUTW), (void*)h->p16_w(4 * l + 1), C * C, st, 1));
+            MGEA_TRY(launch_fold_ln_weights_bf16(h->lw(l, L_FC1W), h->lw(l, L_LN2W), h->lw(l, L_LN2B), h->lw(l, L_FC1B), (void*)h->p16_w(4 * l + 2),
+                                                 h->p16_vec(l, 2), h->p16_vec(l, 3), (int)F, (int)C, st, 1));
+            MGEA_TRY(launch_f32_to_bf16(h->lw(l, L_FC2W), (void*)h->p16_w(4 * l + 3), C * F, st, 1));
+        }
+        MGEA_TRY(launch_f32_to_bf16(h->head_w(), (void*)h->p16_w(4 * (int)NL), V * C, st, 1));
+        p.weights_ready = true;
+    }
+    return MGEA_OK;
+}
+
+int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, int T, float* logits_out, hipStream_t st) {
+    const auto& c = h->cfg;
+    const int C = c.d_model, F = c.d_ff, V = c.vocab, M = B * T, npart = C / 256;
+    MGEA_TRY(ensure_p16(h, M, st));
+    auto& p = h->p16;
+    void *xc = p.x0, *xo = p.x1;
+    const float *id_g = p.ident + p.rows * 2, *id_b = id_g + C;
+    PROF(PC_ROWOP, launch_dec_embed_f16(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), xc, p.rowstat, c.ln_eps, B, T, C, V, c.seq_len,
+                                        c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
+    for (int l = 0; l < c.n_layer; ++l) {
+        const bool last = l + 1 == c.n_layer;
+        const BfEpiLn q{p.rowstat, h->p16_vec(l, 0), nullptr, nullptr, nullptr};
+        PROF(PC_GEMM, launch_gemm_bf16(xc, C, h->p16_w(4 * l + 0), C, h->p16_vec(l, 1), nullptr, p.qkv, 3 * C, M, 3 * C, C, 3, st, nullptr, &q, 1));
+        PROF(PC_ROWOP, launch_kv_scatter_f16(p.qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, (lens && l == 0) ? p.mask : nullptr, B, T,
+                                             C, st));
+        PROF(PC_ATTN_DENSE, launch_attn_bf16(p.qkv, lens ? p.mask : nullptr, p.att, B, T, c.n_head, h->dh, st, 1));
+        const BfEpiLn o{p.ident, nullptr, id_g, id_b, p.stats_part};
+        PROF(PC_GEMM, launch_gemm_bf16(p.att, C, h->p16_w(4 * l + 1), C, h->lw(l, L_OUTB), xc, xo, C, M, C, C, 5, st, nullptr, &o, 1));
+        PROF(PC_ROWOP, launch_ln_rowstat(p.stats_part, p.rowstat, M, npart, C, c.ln_eps, st));
+        const BfEpiLn f1{p.rowstat, h->p16_vec(l, 2), nullptr, nullptr, nullptr};
+        PROF(PC_GEMM, launch_gemm_bf16(xo, C, h->p16_w(4 * l + 2), C, h->p16_vec(l, 3), nullptr, p.hid, F, M, F, C, 4, st, nullptr, &f1, 1));
+        const BfEpiLn f2{p.ident, nullptr, id_g, id_b, last ? nullptr : p.stats_part};
+        PROF(PC_GEMM, launch_gemm_bf16(p.hid, F, h->p16_w(4 * l + 3), F, h->lw(l, L_FC2B), xo, xc, C, M, C, F, 5, st, nullptr, &f2, 1));
+        if (!last) PROF(PC_ROWOP, launch_ln_rowstat(p.stats_part, p.rowstat, M, npart, C, c.ln_eps, st));
+    }
+    if (logits_out)
+        PROF(PC_GEMM, launch_gemm_bf16(xc, C, h->p16_w(4 * c.n_layer), C, h->head_b(), nullptr, logits_out, V, M, V, C, 6, st, nullptr, nullptr, 1));
+    h->counters[5] += 1;
+    return MGEA_OK;
+}
+
 int do_reset(mgea_decoder* h, int B, int max_len, hipStream_t st) {
     const auto& c = h->cfg;
     MGEA_REQUIRE(B > 0 && B <= c.max_batch, MGEA_ECAPACITY, "batch %d exceeds max_batch %d", B, c.max_batch);
@@ -589,7 +728,10 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     MGEA_REQUIRE(M < (1ll << 30), MGEA_EINVAL, "forward: too many tokens");
     MGEA_TRY(ensure_ws(h, M));
     const bool cache_attn = (!post) && h->host_max_len > 0;
-    if (fused_ok(h, (int)M)) {
+    const bool p16 = !fused_ok(h, (int)M) && prefill16_ok(h, M, cache_attn, logits_out);
+    if (p16) {
+        MGEA_TRY(run_prefill16(h, ids, lens, B, T, logits_out, st));   // computes the logits itself (fp32 output of its head GEMM)
+    } else if (fused_ok(h, (int)M)) {
         MGEA_TRY(launch_embed_stats(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, T, C, V,
                                     c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
         MGEA_TRY(run_blocks_fused(h, main_bufs(h), B, T, lens, cache_attn, st));
@@ -599,7 +741,8 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
                                  V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
         MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
     }
-    if (logits_out && fused_ok(h, (int)M)) {
+    if (p16) {
+    } else if (logits_out && fused_ok(h, (int)M)) {
         SkinnyArgs a{};  // x is k-tiled on the fused path: the head is the skinny LOGITS kernel
         a.w_f16 = h->f16;
         a.M = (int)M; a.A = h->x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
@@ -777,6 +920,7 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
 int mgea_decoder_refresh_weights(mgea_decoder* h, void* stream) {
     MGEA_REQUIRE(h, MGEA_EINVAL, "decoder handle is NULL");
     std::lock_guard<std::mutex> lk(h->mu);
+    h->p16.weights_ready = false;   // rebuilt from the refreshed model copy at the next big-batch prefill
     if (!fused_geometry(h->cfg)) return MGEA_OK;
     return build_tiled_weights(h, (hipStream_t)stream);
 }
@@ -786,6 +930,7 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     free_ws(h);
+    free_p16(h);
     void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv,
                  h->samp_dev, h->err_flag, h->arena_own};
     for (void* q : p)

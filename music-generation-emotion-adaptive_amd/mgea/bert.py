@@ -214,7 +214,11 @@ class BertEngine:
         if ids.dim() != 2:
             raise RuntimeError("input_ids must be [B, S]")
         B, S = ids.shape
-        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.geo["vocab"]):
+        # ids outside the vocabulary: nn.Embedding raises IndexError in the reference.  A HOST tensor (what the tokenizer hands over,
+        # emotion_analysis/inference.py:14-16) is checked here at no GPU cost; a DEVICE tensor is not read back -- that put a host
+        # sync and two reduction kernels in front of every forward (~0.1 ms of idle GPU per [256, 128] batch) -- the embedding
+        # kernel clamps such ids instead.
+        if not ids.is_cuda and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.geo["vocab"]):
             raise IndexError("index out of range in self")
         ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
         m32 = None if mask is None else mask.to(device=self.device, dtype=torch.int32).contiguous()

@@ -302,4 +302,4 @@ class DecoderEngine:
     def stats(self):
         out = (C.c_int64 * 8)()
         check(self.lib.mgea_decoder_stats(self.h, out))
-        return dict(graph_nodes=out[0], graph_replays=out[1], graph_instantiates=out[2], graphs_cached=out[4])
+        return dict(graph_nodes=out[0], graph_replays=out[1], graph_instantiates=out[2], graphs_cached=out[4], prefill16_forwards=out[5])

@@ -29,6 +29,7 @@ for s in $STEPS; do
     benchprof) rm -rf /tmp/bn_$TAG; run benchprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bn_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra || exit 1
                f=$(find /tmp/bn_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
     bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
+    f16tests)  run f16tests 600 python3 -m pytest tests/test_gpu_f16.py -x -q -m gpu -s || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
