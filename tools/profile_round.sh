@@ -1,39 +1,45 @@
 #!/bin/bash
 # All rocprofv3 evidence of a round in one GPU-box call (run from the repo root through gpurun):
-#   bash tools/profile_round.sh r2
+#   bash tools/profile_round.sh r3 <commit>
 # Writes gpurun_out/prof_<tag>/: kernel stats of the f32 headline bench, of the fp16 mode and of the bf16 DistilBERT forward;
-# PMC FETCH_SIZE of the eager twin of the headline generation; PMC MFMA utilisation of the DistilBERT GEMMs; and ONE attempt
-# at --pmc under hipGraph replay with its output kept (it aborted in round 1; evidence, not a retry loop).
-# Counter passes carry --pmc only (no trace domains): the pool refuses the combination.
+# PMC FETCH_SIZE of the DOMINANT kernel only (--kernel-include-regex attn_paged_kernel: 6.1 k counter records per pass instead of
+# 32.6 k -- both profiler aborts of round 2 came from the tool's per-dispatch records on long runs, profiles/README.md) on the
+# eager twin of the headline generation AND under hipGraph replay; PMC MFMA utilisation of the DistilBERT GEMMs.
+# Counter passes carry --pmc only (no trace domains): the pool refuses the combination.  One attempt per pass, no retries; stderr kept.
 set -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
+export MGEA_COMMIT=${2:-unknown}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 T=/tmp/prof_$TAG; rm -rf $T; mkdir -p $T
 stats() { f=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $2; }
 pmc() { f=$(find $1 -name "*counter_collection.csv" | head -1); echo $f; }
+step() {  # step <name> <seconds> <cmd...>: a pass that TIMES OUT ends the script (nothing further touches the GPU)
+  local name=$1 secs=$2; shift 2
+  timeout -k 10 $secs "$@" > $OUT/$name.out 2> $OUT/$name.err; local rc=$?
+  echo "$name rc=$rc" | tee -a $OUT/rc.txt
+  [ $rc -lt 124 ] || exit 1
+  return $rc
+}
+BENCH1="python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra"
+GEN1="python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0"
 
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err && stats $T/bench $OUT/bench_kernel_stats.csv
-echo "bench kernel stats rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/f16 -- python3 tools/f16_prof.py both > $OUT/f16_prof.txt 2>&1 && stats $T/f16 $OUT/f16_kernel_stats.csv
-echo "f16 kernel stats rc=$?"; cat $OUT/f16_prof.txt | grep tokens
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/bert -- python3 tools/bert_prof.py bf16 > $OUT/bert_bf16_prof.txt 2>&1 && stats $T/bert $OUT/bert_bf16_kernel_stats.csv
-echo "bert kernel stats rc=$?"
-MGEA_DECODER_NOGRAPH=1 timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch_bench.err
-echo "pmc fetch rc=$?"
-f=$(pmc $T/pmc_fetch); [ -n "$f" ] && python3 tools/pmc_traffic.py $f FETCH_SIZE > $OUT/pmc_fetch_size_full.json
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $T/pmc_mfma -- python3 tools/bert_prof.py bf16 > $OUT/pmc_mfma_prof.txt 2>&1
-echo "pmc mfma rc=$?"
+step bench_under_rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench -- $BENCH1 && stats $T/bench $OUT/bench_kernel_stats.csv
+grep '^{' $OUT/bench_under_rocprof.out > $OUT/bench_under_rocprof.json
+step f16_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/f16 -- python3 tools/f16_prof.py both && stats $T/f16 $OUT/f16_kernel_stats.csv
+step bert_bf16_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/bert -- python3 tools/bert_prof.py bf16 && stats $T/bert $OUT/bert_bf16_kernel_stats.csv
+step prefill16_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/p16 -- python3 tools/prefill_bench.py f16 && stats $T/p16 $OUT/prefill_f16_kernel_stats.csv
+
+# FETCH_SIZE of the attention kernel only, eager twin of the headline generation
+export MGEA_PMC_COMMAND="MGEA_DECODER_NOGRAPH=1 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex attn_paged_kernel --output-format csv -- $GEN1"
+MGEA_DECODER_NOGRAPH=1 step pmc_fetch_attn_eager 420 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex attn_paged_kernel --output-format csv -d $T/pmc_eager -- $GEN1
+f=$(pmc $T/pmc_eager); [ -n "$f" ] && python3 tools/pmc_traffic.py $f FETCH_SIZE > $OUT/pmc_fetch_size_attn.json
+# the same under hipGraph replay (the run bench.py times): with the filter the tool holds 6.1 k records instead of 32.6 k
+export MGEA_PMC_COMMAND="rocprofv3 --pmc FETCH_SIZE --kernel-include-regex attn_paged_kernel --output-format csv -- $GEN1 (decode steps replayed from the hipGraph)"
+step pmc_fetch_attn_graph 420 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex attn_paged_kernel --output-format csv -d $T/pmc_graph -- $GEN1
+f=$(pmc $T/pmc_graph); [ -n "$f" ] && python3 tools/pmc_traffic.py $f FETCH_SIZE > $OUT/pmc_fetch_size_attn_graph_replay.json
+# MFMA utilisation of the DistilBERT GEMMs
+step pmc_mfma 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-include-regex gemm_bf16_ph_kernel --output-format csv -d $T/pmc_mfma -- python3 tools/bert_prof.py bf16
 f=$(pmc $T/pmc_mfma); [ -n "$f" ] && python3 tools/pmc_mfma.py $f gemm > $OUT/pmc_mfma_util.json
-# one attempt, output kept: --pmc with the decode step replayed from the hipGraph (aborted in round 1)
-timeout -k 10 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/pmc_graph -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 --total-len 72 > $OUT/pmc_under_graph_replay.out 2> $OUT/pmc_under_graph_replay.err
-echo "pmc under graph replay rc=$?" | tee $OUT/pmc_under_graph_replay.rc
-# the full-length generation under graph replay with --pmc (only meaningful if the short attempt above returned 0)
-if grep -q "rc=0" $OUT/pmc_under_graph_replay.rc; then
-  timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/pmc_graph_full -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 > $OUT/pmc_graph_full_bench.json 2> $OUT/pmc_graph_full_bench.err
-  echo "pmc under graph replay, full length rc=$?" | tee -a $OUT/pmc_under_graph_replay.rc
-  f=$(pmc $T/pmc_graph_full); [ -n "$f" ] && python3 tools/pmc_traffic.py $f FETCH_SIZE > $OUT/pmc_fetch_size_graph_replay.json
-fi
-[ -x tools/micro/kernel_floor ] && (timeout -k 5 60 tools/micro/kernel_floor 256; timeout -k 5 60 tools/micro/kernel_floor 128) 2>&1 | grep -v amdgpu.ids > $OUT/kernel_floor.txt
-ls -la $OUT
+ls -la $OUT; cat $OUT/rc.txt
