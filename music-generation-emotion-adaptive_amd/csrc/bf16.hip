@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t*
 //     one wave of each SIMD is in its C-segment (matrix pipe) and the other in its L-segment (LDS + address VALU + DMA
 //     issue) -- instead of both reading, then both fighting for the matrix pipe.
 //   * operands go HBM/L2 -> LDS by LDS-DMA (no staging registers, no ds_write), two 64 KB stages; the loads of a tile are
-//     issued 5-8 phases before its first read and are waited for with a COUNTED vmcnt once per K-tile (4 younger DMAs stay
+//     issued 4-6 phases before its first read and are waited for with a COUNTED vmcnt once per K-tile (6 younger DMAs stay
 //     in flight across it); raw s_barrier only (a __syncthreads() would drain the DMA queue).
 //
 // Hazards, by construction (u = K-tile, stage = u & 1, phases q = 4u + p; L(q) / C(q) of waves 0-3 are intervals 2q / 2q+1,
@@ -347,9 +347,13 @@ __global__ __launch_bounds__(256 * WMW) void gemm_bf16_glds_kernel(const bf16_t*
 //            complete (lgkmcnt(0)) before the barrier that ends its L-segment.  So tile u's B halves are last read in
 //            interval 2(4u+1)+1 and its A halves in interval 2(4u+2)+1.
 //   WAR    : stage u & 1 is refilled with tile u+2: B-half 0 issued in phase 4u+2 (first interval 2(4u+2) > 2(4u+1)+1),
-//            A-half 0 in phase 4u+3 (2(4u+3) > 2(4u+2)+1), B-half 1 / A-half 1 in phases 4(u+1), 4(u+1)+1.
-//   RAW    : tile u+1 is first read in interval 2*4(u+1) = 8u+8.  Its last DMA (A-half 1) is issued in phase 4u+1; every wave
-//            waits until ITS DMAs of tile u+1 have landed -- vmcnt(4): only the two half-tiles issued in phases 4u+2, 4u+3
+//            BOTH A halves in phase 4u+3 (2(4u+3) > 2(4u+2)+1), B-half 1 in phase 4(u+1).
+//            (Round 2 issued A-half 1 in phase 4(u+1)+1, three phases before its first read: A is the operand that misses L2 -- an
+//            A panel is shared by N / 256 tiles only, the W panel by every row tile of the XCD's run -- and in-kernel stamps
+//            (tools/gemm_bf16_stamps.py) showed the K loop of the N = 768 GEMMs at 2.0 us per K-tile against 1.45 at N >= 2304.
+//            The A halves now have the longest lookahead, 5 phases, the L2-resident B-half 1 the shortest, 4.)
+//   RAW    : tile u+1 is first read in interval 2*4(u+1) = 8u+8.  Its last DMA (B-half 1) is issued in phase 4u; every wave
+//            waits until ITS DMAs of tile u+1 have landed -- vmcnt(6): only the three half-tiles issued in phases 4u+2, 4u+3
 //            may still be in flight -- at the end of interval 8u+7 (waves 0-3: end of C(4u+3); waves 4-7: end of L(4u+3)),
 //            and the barrier that ends that interval publishes them to every wave.
 // One 1 KiB LDS-DMA piece (64 lanes x 16 B, LDS destination = wave-uniform byte address + 16 * lane) issued from inline
@@ -399,6 +403,16 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 #undef MGEA_ROR_ADD
     return v + __shfl_xor(v, 16, 64);
 }
+
+// In-kernel time stamps of the persistent GEMM (cdna_hip_programming.md section 7), compiled ONLY into the tools build
+// (tools/build_stamps.sh: -DMGEA_PH_STAMPS, a separate .so that tools/gemm_bf16_stamps.py loads); the product library has none of it.
+#ifdef MGEA_PH_STAMPS
+__device__ unsigned long long* g_ph_stamps = nullptr;      // [workgroup][64] 100 MHz ticks, written by thread 0
+#define PH_STAMP(i) do { if (g_ph_stamps && tid == 0 && (i) < 64) g_ph_stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int mgea_dbg_set_ph_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamps), &p, sizeof(p)); }
+#else
+#define PH_STAMP(i) do { } while (0)
+#endif
 
 template <int EPI, typename T>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // groups as above: L(q) / C(q) = intervals 2q / 2q+1 resp. 2q+1 / 2q+2):
     //   reads : p0 reads W(j=0) + A, p1 reads W(j=1); every ds_read complete (lgkmcnt(0)) before the barrier that ends its L-segment,
     //           so stage u % 3 is last read in interval 2(2u+1)+1 = 4u+3.
-    //   WAR   : stage (u+3) % 3 = u % 3 is refilled with K-tile u+3 in phases 2(u+1) (W0) and 2(u+1)+1 (A0, W1), first interval
+    //   WAR   : stage (u+3) % 3 = u % 3 is refilled with K-tile u+3 in phases 2(u+1) (A0) and 2(u+1)+1 (W0, W1), first interval
     //           2(2u+2) = 4u+4 > 4u+3.
     //   RAW   : K-tile u+1 is first read in interval 2*2(u+1) = 4u+4; all its DMAs were issued in phases 2u-2, 2u-1 (or the
     //           prologue); every wave waits for ITS pieces at the end of interval 4u+3 (early: end of C(2u+1), late: end of
@@ -511,12 +525,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
             glds16_hidden(src[hid][i] + kt * 64, dst);
         }
     };
-    // whole tiles: tile 0 whole, then the first two half-tiles of tile 1 (the steady state issues W0 / A0 of K-tile u+2 in phases
-    // 4u+2 / 4u+3 and W1 / A1 of K-tile u+1 in phases 4u / 4u+1); half units: K-tiles 0 and 1 whole (6 + 6 DMAs per wave)
+    // whole tiles: tile 0 whole, then W0 / A0 / A1 of tile 1 (the steady state issues W0 and A0 + A1 of K-tile u+2 in phases 4u+2
+    // and 4u+3, W1 of K-tile u+1 in phase 4u); half units: K-tiles 0 and 1 whole (6 + 6 DMAs per wave)
     auto issue_prologue = [&](int nkt, int md) {
         if (md == 0) {
             issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
-            if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); }
+            if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); issue_half(1, 1); }
         } else {
             issue_h(2, 0, 0); issue_h(0, 0, 0); issue_h(3, 0, 0);
             if (nkt > 1) { issue_h(2, 1, 1); issue_h(0, 1, 1); issue_h(3, 1, 1); }
@@ -529,6 +543,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     while (have) {
         const int cm0 = m0, cn0 = n0;                       // this unit's origin (set_tile moves on to the next one below)
         const int nkt = KT, mode = u_mode;
+        const int sbase = ui * 12;
+        PH_STAMP(sbase + 0);                                // unit start
         const bool halfu = mode != 0;                       // workgroup-uniform
         const int wrows = halfu ? 64 : 128;                 // rows of the unit per wave row wm
         f32x4 acc[4][8];             // [n-tile of 16 columns][m-tile of 16 rows]
@@ -536,17 +552,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // K-tile 0 has landed when at most the DMAs of K-tile 1 issued by the prologue (4 for a whole tile, 6 for a half unit) are
-        // still in flight.  (After the first unit the previous epilogue's stores are younger than these DMAs and count too: the
+        // K-tile 0 has landed when at most the 6 DMAs of K-tile 1 issued by the prologue (W0 / A0 / A1 of a whole tile, all of a half
+        // unit's) are still in flight.  (After the first unit the previous epilogue's stores are younger than these DMAs and count too: the
         // wait is then stronger, never weaker.)
         if (nkt > 1) {
-            if (halfu) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
+        PH_STAMP(sbase + 1);                                // K-tile 0 landed, K loop starts
 
         v8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
         if (!halfu) {
@@ -578,12 +594,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (p == 0 && u + 1 < nkt) issue_half(3, u + 1);
-                if (p == 1 && u + 1 < nkt) issue_half(1, u + 1);
                 if (p == 2 && u + 2 < nkt) issue_half(2, u + 2);
-                if (p == 3 && u + 2 < nkt) issue_half(0, u + 2);
+                if (p == 3 && u + 2 < nkt) { issue_half(0, u + 2); issue_half(1, u + 2); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
                 if (p == 3 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(4u+3) ...
-                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         }
                 __builtin_amdgcn_s_setprio(0);
                 if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
-                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -636,8 +651,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (p == 0 && u + 2 < nkt) issue_h(2, u + 2, st3n);
-                if (p == 1 && u + 2 < nkt) { issue_h(0, u + 2, st3n); issue_h(3, u + 2, st3n); }
+                if (p == 0 && u + 2 < nkt) issue_h(0, u + 2, st3n);                                 // A first: the operand that misses L2
+                if (p == 1 && u + 2 < nkt) { issue_h(2, u + 2, st3n); issue_h(3, u + 2, st3n); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (p == 1 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(2u+1) ...
                     if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -669,23 +684,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         }
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
+        PH_STAMP(sbase + 2);                                // K loop done
 
-        // Both operand stages are free now (every read of the last K-tiles completed before the barriers above): put the NEXT
-        // tile's first DMAs in flight before this tile's epilogue, so their latency runs under it.
-        float4 bv[4];                                          // this tile's bias for the lane's 4 x 4 columns, before the DMAs
+        // Both operand stages are free now (every read of the last K-tiles completed before the barriers above).  Epilogues without a
+        // residual put the NEXT unit's first DMAs in flight right here, so their latency runs under the whole epilogue.  The residual
+        // epilogues (RESV) first request ALL residual rows of the unit and issue those DMAs one LDS pass later, behind an explicit
+        // wait: hipcc counts only the loads it can see, so with hidden DMAs in flight every wait it inserts for a residual row is a
+        // wait for (most of) the DMAs too, and vmcnt retires in order anyway -- round 2 prefetched the residual one pass ahead and
+        // in-kernel stamps (tools/gemm_bf16_stamps.py) showed every pass of an epilogue-5 tile sitting through a 2-3 us round trip
+        // (16.5 us outside the K loop against 6.5 for epilogue 0).  The residual rows of passes 0 and 1 are requested up front (older
+        // than the DMAs); those of pass k + 2 at the end of pass k, into the registers it has freed -- younger than the DMAs, which
+        // have had two passes to land by the time these are waited for.  (All four passes up front: 96 more live registers, 40 spilled.)
+        float4 bv[4];                                          // !RESV: this unit's bias for the lane's 4 x 4 columns, before the DMAs
+        if (!RESV) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int col = cn0 + wn * 64 + n * 16 + 4 * g;
-            bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int n = 0; n < 4; ++n) {
+                const int col = cn0 + wn * 64 + n * 16 + 4 * g;
+                bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         have = get_unit(++ui);
-        if (have) { set_tile(u_tile, u_mode); issue_prologue(KT, u_mode); }
+        if (have) set_tile(u_tile, u_mode);
+        if (!RESV && have) issue_prologue(KT, u_mode);
 
         const int kpass = halfu ? 2 : 4;                       // epilogue passes of 2 m-tiles per wave row (a half unit has 4 m-tiles)
+        PH_STAMP(sbase + 3);                                // next unit's prologue issued (RESV: only its addresses are ready)
         // Epilogue through the 32 KB C stage in 4 passes of 64 rows (m-tiles 2k, 2k+1 of both wave rows): bias / GELU in registers,
         // bf16 rows staged with the 16-byte chunk XOR-swizzled by the row (the 16 rows a ds_write touches would otherwise share
-        // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual is added on the way
-        // out.  Raw barriers + lgkmcnt only: a __syncthreads() would wait for the DMAs just issued.
+        // their banks: the row pitch is 512 B), streamed out as whole rows, 16 bytes per lane; the residual (and, with it, the bias)
+        // is added on the way out.  Raw barriers + lgkmcnt only: a __syncthreads() would wait for the DMAs in flight.
         unsigned char* sC = reinterpret_cast<unsigned char*>(lds + CST);
         // LayerNorm folded into this GEMM (LNF): this lane's rows' (mean, rstd) and its columns' c1 = sum_k W'[n, k]
         float mu[8], rs[8];
@@ -704,33 +731,37 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 c1v[n] = col < N ? ld4(ln.c1 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        // Residual rows one pass ahead: loaded where they are used, behind the pass's barrier, every pass of every workgroup sat
-        // through a load round trip in the middle of the chip-wide store burst (FC2: 34 of 168 us were residual loads + stores).
-        // RES_LN: the residual is LayerNorm(res row) -- the raw row comes with its (mean, rstd), gamma / beta of this thread's 8
-        // columns are loaded once per tile (a thread keeps its 16-byte chunk index through all passes).
-        v8 rnext[4];
-        float2 snext[4];
-        const int my_col = cn0 + (tid & 31) * 8;
-        // (unconditional loads: a load behind a run-time branch makes hipcc wait vmcnt(0) right after it, which put a full round trip
-        // into every pass; an already-normalised residual therefore comes with an identity table: mean 0, rstd 1, gamma 1, beta 0.
-        // N % 256 == 0 for this epilogue, so the 8 columns are always in range)
-        float4 gam0, gam1, bet0, bet1;
-        if (EPI == BEPI_RES_LN) {
-            gam0 = ld4(ln.ln_g + my_col); gam1 = ld4(ln.ln_g + my_col + 4);
-            bet0 = ld4(ln.ln_b + my_col); bet1 = ld4(ln.ln_b + my_col + 4);
-        }
-        auto load_res = [&](int k) {
+        // RES_LN: the residual is LayerNorm(res row) -- the raw row comes with its (mean, rstd); gamma / beta of this thread's 8
+        // columns are loaded once per unit (a thread keeps its 16-byte chunk index through all passes), the bias joins beta.
+        // (An already-normalised residual comes with identity tables -- mean 0, rstd 1, gamma 1, beta 0 -- not with a null pointer.
+        // N % 256 == 0 for the LayerNorm epilogues, so the 8 columns are always in range; the plain residual epilogue clamps.)
+        v8 rr[2][4];                                          // ring of two passes
+        f32x2 ss[2][4];
+        auto load_res = [&](int k, v8 (&rd)[4], f32x2 (&sd)[4]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int id = tid + i * 512, prow = id >> 5, ch = id & 31;
                 const int lrow = (prow >> 5) * wrows + (2 * k + ((prow >> 4) & 1)) * 16 + (prow & 15);
                 int row = cm0 + lrow, col = cn0 + ch * 8;
                 row = row < M ? row : M - 1; col = col < N ? col : 0;         // clamped: loaded, not used
-                rnext[i] = *reinterpret_cast<const v8*>(res + (int64_t)row * ldc + col);
-                if (EPI == BEPI_RES_LN) snext[i] = *reinterpret_cast<const float2*>(ln.rowstat + (int64_t)row * 2);
+                rd[i] = *reinterpret_cast<const v8*>(res + (int64_t)row * ldc + col);
+                if (EPI == BEPI_RES_LN) sd[i] = *reinterpret_cast<const f32x2*>(ln.rowstat + (int64_t)row * 2);
             }
         };
-        if (RESV) load_res(0);
+        const int my_col = cn0 + (tid & 31) * 8;
+        f32x4 gam0, gam1, bet0, bet1;
+        if (RESV) {
+            auto ldv4 = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+            const int bc = my_col < N ? my_col : 0;
+            bet0 = bias ? ldv4(bias + bc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            bet1 = bias ? ldv4(bias + bc + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (EPI == BEPI_RES_LN) {
+                gam0 = ldv4(ln.ln_g + my_col); gam1 = ldv4(ln.ln_g + my_col + 4);
+                bet0 += ldv4(ln.ln_b + my_col); bet1 += ldv4(ln.ln_b + my_col + 4);
+            }
+            load_res(0, rr[0], ss[0]);
+            load_res(1, rr[1], ss[1]);                         // (kpass >= 2 always)
+        }
         if constexpr (EPI != BEPI_BIAS_F32) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -746,7 +777,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                     if (LNF)   // rstd (A W'^T - mean c1) + c2, c2 in the bias slot
                         v = make_float4(rs[m] * fmaf(-mu[m], c1v[n].x, v.x), rs[m] * fmaf(-mu[m], c1v[n].y, v.y),
                                         rs[m] * fmaf(-mu[m], c1v[n].z, v.z), rs[m] * fmaf(-mu[m], c1v[n].w, v.w));
-                    v = add4(v, bv[n]);
+                    if (!RESV) v = add4(v, bv[n]);
                     if (EPI == BEPI_BIAS_GELU || EPI == BEPI_LNFOLD_GELU) {
                         const f32x2 g0 = gelu_fast2((f32x2){v.x, v.y}), g1 = gelu_fast2((f32x2){v.z, v.w});
                         v = make_float4(g0[0], g0[1], g1[0], g1[1]);
@@ -758,12 +789,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            v8 rcur[4];
-            float2 scur[4];
-            if (RESV) {
+            PH_STAMP(sbase + 4 + 2 * k);                        // pass k staged
+            if (RESV && k == 0) {
+                // every residual chunk of the unit has landed (and the compiler is told so: the empty statements "write" the registers,
+                // so no wait of its own can follow once the hidden DMAs are in flight); only now the next unit's first DMAs
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { rcur[i] = rnext[i]; scur[i] = snext[i]; }
-                if (k + 1 < kpass) load_res(k + 1);
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        asm volatile("" : "+v"(rr[kk][i]));
+                        if (EPI == BEPI_RES_LN) asm volatile("" : "+v"(ss[kk][i]));
+                    }
+                asm volatile("" : "+v"(bet0), "+v"(bet1));
+                if (EPI == BEPI_RES_LN) asm volatile("" : "+v"(gam0), "+v"(gam1));
+                if (have) issue_prologue(KT, u_mode);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
@@ -777,11 +817,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 // the two fp32 values.
                 u32x4 vw = *reinterpret_cast<const u32x4*>(sC + prow * 512 + ((ch ^ (prow & 31)) * 16));
                 if (RESV) {
-                    const u32x4 rw = __builtin_bit_cast(u32x4, rcur[i]);
+                    const u32x4 rw = __builtin_bit_cast(u32x4, rr[k & 1][i]);
                     // LayerNorm of the residual row: (r - mean) rstd gamma + beta = (r a + b) gamma + beta with a = rstd, b = -mean rstd
-                    const float ra = scur[i].y, rb = -scur[i].x * scur[i].y;
-                    const f32x2 gam2[4] = {{gam0.x, gam0.y}, {gam0.z, gam0.w}, {gam1.x, gam1.y}, {gam1.z, gam1.w}};
-                    const f32x2 bet2[4] = {{bet0.x, bet0.y}, {bet0.z, bet0.w}, {bet1.x, bet1.y}, {bet1.z, bet1.w}};
+                    // (beta carries the GEMM's bias too)
+                    const float ra = ss[k & 1][i][1], rb = -ss[k & 1][i][0] * ss[k & 1][i][1];
+                    const f32x2 gam2[4] = {{gam0[0], gam0[1]}, {gam0[2], gam0[3]}, {gam1[0], gam1[1]}, {gam1[2], gam1[3]}};
+                    const f32x2 bet2[4] = {{bet0[0], bet0[1]}, {bet0[2], bet0[3]}, {bet1[0], bet1[1]}, {bet1[2], bet1[3]}};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x2 x = X16<T>::unpack(vw[q]);
@@ -789,6 +830,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         if (EPI == BEPI_RES_LN) {
                             r = __builtin_elementwise_fma(r, (f32x2){ra, ra}, (f32x2){rb, rb});
                             r = __builtin_elementwise_fma(r, gam2[q], bet2[q]);
+                        } else {
+                            r = r + bet2[q];                           // the bias
                         }
                         x = x + r;
                         const v2 o = {(T)x[0], (T)x[1]};
@@ -817,8 +860,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         *reinterpret_cast<float2*>(ln.stats_out + ((int64_t)row * tiles_n + (cn0 >> 8)) * 2) = make_float2(s1, s2);
                 }
             }
+            if (RESV && k + 2 < kpass) load_res(k + 2, rr[k & 1], ss[k & 1]);   // the slot this pass has just consumed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                     // the C stage is rewritten by the next pass
+            PH_STAMP(sbase + 5 + 2 * k);                        // pass k read out, stores issued
         }
         } else {
             // fp32 rows: 8 passes (4 for a half unit) of 32 rows -- m-tile k of both wave rows -- through the same 32 KB C stage:

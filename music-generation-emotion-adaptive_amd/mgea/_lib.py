@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgea_hip.so")
+# (MGEA_LIB_PATH: tools/ only -- an instrumented build of the same library, e.g. tools/libmgea_hip_stamps.so)
+LIB_PATH = os.environ.get("MGEA_LIB_PATH") or os.path.join(_HERE, "libmgea_hip.so")
 
 OK, EINVAL, ENOMEM, EHIP, ECAPACITY, ENODEVICE = 0, -1, -2, -3, -4, -5
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2

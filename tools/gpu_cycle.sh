@@ -30,6 +30,7 @@ for s in $STEPS; do
                f=$(find /tmp/bn_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
     bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
     f16tests)  run f16tests 600 python3 -m pytest tests/test_gpu_f16.py -x -q -m gpu -s || exit 1 ;;
+    stamps)    run stamps 300 python3 tools/gemm_bf16_stamps.py || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
