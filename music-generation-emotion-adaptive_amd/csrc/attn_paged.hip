@@ -77,11 +77,14 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NCH; ++i) kk[i] = ldraw(kpage + (i * 64 + tok) * 16);
     };
-    // The first K tile is requested before anything else is known: its page index depends only on the
-    // wave id, so the page-table -> K round trips overlap the ctx_len / q fetches (the kernel's fixed
-    // latency is what short contexts pay).  A wave beyond the row's pages reads a reserved (zeroed or
-    // stale but mapped) page and drops it.
-    load_k(wave < max_pages ? wave : max_pages - 1, 64);   // length not known yet: whole page
+    // Wave 0's first K tile (page 0 always holds a token) is requested before anything else is known, so that the page-table -> K
+    // round trips overlap the ctx_len / q fetches; the length is not known yet: the whole page.  Waves 1..3 wait for the length
+    // (one scalar round trip) and then request exactly the tokens their first page holds -- or nothing: in round 2 they too read
+    // a whole page up front, 24 MB per launch at B x H = 512 that below 256 tokens of context nobody needs
+    // (profiles/r3_attn_early_v_ab_by_ctx.txt: that burst, not a latency chain, was most of the 8.6 us a launch took at short
+    // contexts).  Above 256 tokens their first pages are full and they start ~0.7 us later than wave 0, which has as many pages or
+    // one more.
+    if (wave == 0) load_k(0, 64);
 
     const int n_new = lens ? lens[b] : T;
     auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d, C) : out + m * C + h * DH + d; };
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     }
     const int len = ctx_len[b] + n_new;  // tokens visible to this query (whole cache, no mask)
     const int npages = (len + 63) >> 6;
+    if (wave != 0 && wave < npages) load_k(wave, len - wave * 64);
 
     const float* qp = qkv + m * 3 * C + h * DH;
     float q[DH];

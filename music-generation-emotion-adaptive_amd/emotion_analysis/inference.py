@@ -35,9 +35,13 @@ def _logits(text: Union[str, Sequence[str]]) -> torch.Tensor:
 
 
 def predict(text: str) -> str:
-    """Emotion label of one text (inference.py:12-22): argmax over the 28 logits."""
-    logits = _logits(text)
-    return ID2LABEL[int(torch.argmax(logits, dim=1).item())]
+    """Emotion label of one text (inference.py:12-22): argmax over the 28 logits -- the engine's own device argmax
+    (ties to the lowest id, like torch.argmax), so no torch arithmetic sits between the kernels and the label."""
+    if model is None:
+        configure()
+    inputs = tokenizer(text, return_tensors="pt", truncation=True, padding=True)     # inference.py:16
+    _, amax = model.forward(inputs["input_ids"], inputs["attention_mask"], want_logits=False)
+    return ID2LABEL[int(amax[0])]
 
 
 def classify(text: Union[str, Sequence[str], torch.Tensor], attention_mask: Optional[torch.Tensor] = None):

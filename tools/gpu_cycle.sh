@@ -31,6 +31,8 @@ for s in $STEPS; do
     bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
     f16tests)  run f16tests 600 python3 -m pytest tests/test_gpu_f16.py -x -q -m gpu -s || exit 1 ;;
     stamps)    run stamps 300 python3 tools/gemm_bf16_stamps.py || exit 1 ;;
+    attnctx)   rm -rf /tmp/ac_$TAG; run attnctx 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/ac_$TAG -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 || exit 1
+               f=$(find /tmp/ac_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/attn_vs_ctx.py $f > $OUT/attn_vs_ctx.txt && python3 tools/kernels_vs_ctx.py $f > $OUT/kernels_vs_ctx.txt; head -30 $OUT/attn_vs_ctx.txt ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
