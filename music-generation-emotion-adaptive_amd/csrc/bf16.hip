@@ -493,8 +493,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
             }
     };
-    auto issue_half = [&](int hid, int kt) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
-        const int stage = kt & 1;
+    auto issue_half = [&](int hid, int kt, int stage) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
@@ -529,20 +528,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // and 4u+3, W1 of K-tile u+1 in phase 4u); half units: K-tiles 0 and 1 whole (6 + 6 DMAs per wave)
     auto issue_prologue = [&](int nkt, int md) {
         if (md == 0) {
-            issue_half(2, 0); issue_half(0, 0); issue_half(3, 0); issue_half(1, 0);
-            if (nkt > 1) { issue_half(2, 1); issue_half(0, 1); issue_half(1, 1); }
+            issue_half(2, 0, 0); issue_half(0, 0, 0); issue_half(3, 0, 0); issue_half(1, 0, 0);
+            if (nkt > 1) { issue_half(2, 1, 1); issue_half(0, 1, 1); issue_half(1, 1, 1); }
         } else {
             issue_h(2, 0, 0); issue_h(0, 0, 0); issue_h(3, 0, 0);
             if (nkt > 1) { issue_h(2, 1, 1); issue_h(0, 1, 1); issue_h(3, 1, 1); }
         }
     };
 
-    int ui = 0;
+    // STREAM ACROSS WHOLE TILES: when this unit and the next are both whole tiles, the LDS-DMA schedule simply continues over the
+    // boundary -- the "K-tile u+1 / u+2" of the last two K-tiles are the next unit's K-tiles 0 / 1 (their source addresses replace this
+    // unit's in phase 1 of K-tile nkt-2, after this unit's last DMA and before the next unit's first) -- instead of a burst of 14 DMAs
+    // per wave between the K loop and the epilogue (stamps: 1.7 us per tile during which all 8 waves only issue, and K-tile 0 / 1 get
+    // half the lookahead).  Stages keep alternating: the next unit reads K-tile v from stage (v + sb) & 1, sb = (sb + nkt) & 1.
+    // The hazard analysis above is unchanged: it is the same schedule with tile indices taken modulo the unit.  Units next to a half
+    // unit (other stage geometry) and single-K-tile units start from the burst as before, with sb = 0.
+    int ui = 0, sb = 0;
     bool have = get_unit(0);
-    if (have) { set_tile(u_tile, u_mode); issue_prologue(KT, u_mode); }
+    int cur_tile = u_tile, cur_mode = u_mode;
+    if (have) { set_tile(cur_tile, cur_mode); issue_prologue(KT, cur_mode); }
     while (have) {
         const int cm0 = m0, cn0 = n0;                       // this unit's origin (set_tile moves on to the next one below)
-        const int nkt = KT, mode = u_mode;
+        const int nkt = KT, mode = cur_mode;
+        const bool nx_have = get_unit(ui + 1);              // peek: u_tile / u_mode now describe the NEXT unit
+        const int nx_tile = u_tile, nx_mode = u_mode;
+        const bool stream = nx_have && nx_mode == 0 && mode == 0 && nkt >= 2;
         const int sbase = ui * 12;
         PH_STAMP(sbase + 0);                                // unit start
         const bool halfu = mode != 0;                       // workgroup-uniform
@@ -567,9 +577,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         v8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
         if (!halfu) {
         for (int u = 0; u < nkt; ++u) {
-            const float4* sb = lds + (u & 1) * STAGE;
-            const float4* sa = sb + (wm * 128) * 8;
-            const float4* sw = sb + SA + (wn * 64) * 8;
+            const float4* sbuf = lds + ((u + sb) & 1) * STAGE;
+            const float4* sa = sbuf + (wm * 128) * 8;
+            const float4* sw = sbuf + SA + (wn * 64) * 8;
+            const int g1 = u + 1, g2 = u + 2;               // K-tiles the DMAs of this K-tile belong to (>= nkt: the next unit's)
+            const bool i1 = g1 < nkt || stream, i2 = g2 < nkt || stream;
+            const int k1 = g1 < nkt ? g1 : g1 - nkt, k2 = g2 < nkt ? g2 : g2 - nkt;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // ---------------- L-segment
@@ -593,13 +606,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (p == 0 && u + 1 < nkt) issue_half(3, u + 1);
-                if (p == 2 && u + 2 < nkt) issue_half(2, u + 2);
-                if (p == 3 && u + 2 < nkt) { issue_half(0, u + 2); issue_half(1, u + 2); }
+                if (p == 0 && i1) issue_half(3, k1, (g1 + sb) & 1);
+                if (p == 1 && stream && u == nkt - 2) set_tile(nx_tile, 0);   // this unit's last DMA is out: the next unit's addresses
+                if (p == 2 && i2) issue_half(2, k2, (g2 + sb) & 1);
+                if (p == 3 && i2) { issue_half(0, k2, (g2 + sb) & 1); issue_half(1, k2, (g2 + sb) & 1); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
                 if (p == 3 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(4u+3) ...
-                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (i2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -617,8 +631,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         }
                 __builtin_amdgcn_s_setprio(0);
                 if (p == 3 && wm == 0) {     // ... the early group at the end of its C(4u+3): the same interval
-                    if (u + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (i2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -703,9 +717,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 bv[n] = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        have = get_unit(++ui);
-        if (have) set_tile(u_tile, u_mode);
-        if (!RESV && have) issue_prologue(KT, u_mode);
+        ++ui;
+        have = nx_have;
+        cur_tile = nx_tile; cur_mode = nx_mode;
+        if (have && !stream) set_tile(nx_tile, nx_mode);   // (stream: done inside the K loop, and the next unit's K-tile 0 has landed)
+        if (!RESV && have && !stream) issue_prologue(KT, nx_mode);
+        sb = stream ? (sb + nkt) & 1 : 0;
 
         const int kpass = halfu ? 2 : 4;                       // epilogue passes of 2 m-tiles per wave row (a half unit has 4 m-tiles)
         PH_STAMP(sbase + 3);                                // next unit's prologue issued (RESV: only its addresses are ready)
@@ -803,7 +820,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                     }
                 asm volatile("" : "+v"(bet0), "+v"(bet1));
                 if (EPI == BEPI_RES_LN) asm volatile("" : "+v"(gam0), "+v"(gam1));
-                if (have) issue_prologue(KT, u_mode);
+                if (have && !stream) issue_prologue(KT, nx_mode);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                      // 64 rows x 32 chunks = 2048 chunks / 512 threads
