@@ -204,7 +204,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         for (int64_t& e : h->last_epi) e = 0;
         auto bgemm = [&](const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C, int ldc, int m, int n,
                          int k, int epi, const BfEpiLn* ln = nullptr) -> int {
-            GemmBf16Info gi{0, 0};
+            GemmBf16Info gi{0, 0, k > n ? 1 : 0};   // the FFN down-projection (K = hidden > N) reads the up-projection's big output: walk it backwards
             MGEA_TRY(launch_gemm_bf16(A, lda, W, ldw, bias, res, C, ldc, m, n, k, epi, st, &gi, ln));
             (gi.kernel == 2 ? h->last_persistent : gi.kernel == 1 ? h->last_ring : h->last_small) += 1;
             h->last_half_tiles += gi.half_tiles;

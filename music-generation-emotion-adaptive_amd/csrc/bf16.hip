@@ -451,26 +451,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // bitwise identical.  tail_mode 2 additionally lets the odd slots run their half unit FIRST, so that the two halves of the chip
     // reach their store bursts half a tile apart.
     const int full_rounds = per_x > 0 ? per_x / wg_x : 0, rem = per_x > 0 ? per_x - full_rounds * wg_x : 0;
-    const bool split = tail_mode != 0 && rem > 0 && 2 * rem <= wg_x;
-    const bool half_first = split && tail_mode == 2 && (slot & 1) && slot < 2 * rem;
+    const bool split = (tail_mode & 3) != 0 && rem > 0 && 2 * rem <= wg_x;
+    const bool half_first = split && (tail_mode & 3) == 2 && (slot & 1) && slot < 2 * rem;
     int u_tile = 0, u_mode = 0;                              // mode 0: whole tile, 1 / 2: rows 0..127 / 128..255 of a shared tile
+    // (tail_mode bit 2 = walk the XCD's run of tiles from its END: a GEMM whose A operand is the previous kernel's output and larger
+    // than what the 256 MB Infinity Cache keeps of it -- DistilBERT's FC2 reads FC1's 201 MB -- otherwise reads that operand in the
+    // order it was written, the one order in which an LRU cache that has just lost the head of the stream misses on every line)
+    const bool rev = (tail_mode & 4) != 0;
+    auto run_tile = [&](int idx) { return run0 + (rev ? per_x - 1 - idx : idx); };
     auto get_unit = [&](int ui) -> bool {                   // the ui-th unit of this workgroup
         if (half_first) {                                    // the tail unit comes first, the whole tiles after it
-            if (ui == 0) { u_tile = run0 + full_rounds * wg_x + (slot >> 1); u_mode = 1 + (slot & 1); return true; }
+            if (ui == 0) { u_tile = run_tile(full_rounds * wg_x + (slot >> 1)); u_mode = 1 + (slot & 1); return true; }
             ui -= 1;
-            if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_mode = 0; return true; }
+            if (ui < full_rounds) { u_tile = run_tile(slot + ui * wg_x); u_mode = 0; return true; }
             return false;
         }
-        if (ui < full_rounds) { u_tile = run0 + slot + ui * wg_x; u_mode = 0; return true; }
+        if (ui < full_rounds) { u_tile = run_tile(slot + ui * wg_x); u_mode = 0; return true; }
         if (ui > full_rounds) return false;
         if (split) {
             if (slot >= 2 * rem) return false;
-            u_tile = run0 + full_rounds * wg_x + (slot >> 1);
+            u_tile = run_tile(full_rounds * wg_x + (slot >> 1));
             u_mode = 1 + (slot & 1);
             return true;
         }
         if (slot >= rem) return false;
-        u_tile = run0 + full_rounds * wg_x + slot; u_mode = 0;
+        u_tile = run_tile(full_rounds * wg_x + slot); u_mode = 0;
         return true;
     };
 
@@ -925,12 +930,12 @@ static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias
     const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
     const int n_cu = di.n_cu / 8 * 8;
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
-    const int tail = tune(TUNE_BF16_GEMM_TAIL);
+    const int tail = (tune(TUNE_BF16_GEMM_TAIL) & 3) | ((info && info->reverse && tune(TUNE_BF16_GEMM_REVERSE)) ? 4 : 0);
     if (info) {   // what the kernel will do with the tiles left after the full rounds (the same arithmetic as in the kernel, XCD run 0)
         const int wg_x = grid / 8, per_x = (n_tiles + 7) / 8 < n_tiles ? (n_tiles + 7) / 8 : n_tiles;
         const int rem = per_x - per_x / wg_x * wg_x;
         info->kernel = 2;
-        info->half_tiles = (tail != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
+        info->half_tiles = ((tail & 3) != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
     }
     hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
                        tail, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});

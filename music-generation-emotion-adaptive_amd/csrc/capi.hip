@@ -24,7 +24,8 @@ namespace {
 struct TuneEntry { const char* name; const char* env; int dflt; };
 const TuneEntry kTune[TUNE_COUNT] = {
     {"bf16_gemm_tile", "MGEA_BF16_GEMM_TILE", 0},     {"bf16_gemm_small", "MGEA_BF16_GEMM_SMALL", 0},
-    {"bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},     {"bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
+    {"bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},     {"bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
+    {"bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
     {"decoder_unfused", "MGEA_DECODER_UNFUSED", 0},   {"decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
     {"decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},   {"decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
 };
@@ -149,7 +150,7 @@ int mgea_op_gemm_bf16_ln(const void* a_dev, const void* w_dev, const float* bias
                          const float* ln_g_dev, const float* ln_b_dev, float* stats_out_dev, int32_t* info_out, void* stream) {
     MGEA_REQUIRE(a_dev && w_dev && out_dev, MGEA_EINVAL, "op_gemm_bf16_ln: NULL argument");
     const BfEpiLn ln{rowstat_dev, c1_dev, ln_g_dev, ln_b_dev, stats_out_dev};
-    GemmBf16Info gi{-1, 0};
+    GemmBf16Info gi{-1, 0, 0};
     const int rc = launch_gemm_bf16(a_dev, K, w_dev, K, bias_dev, res_dev, out_dev, N, M, N, K, epi, (hipStream_t)stream, &gi,
                                     epi >= 3 ? &ln : nullptr);
     if (info_out) { info_out[0] = gi.kernel; info_out[1] = gi.half_tiles; }

@@ -43,6 +43,7 @@ const char* get_error();
 enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 256x128 / 3 256x256 ring kernels; 4 = the persistent 256x256 kernel
        TUNE_BF16_GEMM_SMALL,      // 1: the register-staged 128x128 kernel for every shape
        TUNE_BF16_GEMM_TAIL,       // persistent kernel, tiles left after the full rounds: 0 whole tiles, 1 two 128-row halves, 2 = 1 + staggered order
+       TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
        TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
@@ -228,7 +229,9 @@ struct BfEpiLn { const float* rowstat; const float* c1; const float* ln_g; const
 // What a launch_gemm_bf16 call ran (optional out-parameter; the engines count these for mgea_bert_stats): kernel 0 = the
 // register-staged 128 x 128 kernel, 1 = a ring kernel, 2 = the persistent phase-interleaved 256 x 256 kernel; half_tiles = 1 when that
 // kernel cuts the tiles left over after its full rounds into two 128-row halves (bf16.hip, "HALF-TILE TAIL").
-struct GemmBf16Info { int kernel; int half_tiles; };
+// reverse (IN): ask the persistent kernel to walk its tiles from the end of every XCD's run (switch bf16_gemm_reverse; for a GEMM whose A
+// operand is the previous kernel's large output: see the kernel).
+struct GemmBf16Info { int kernel; int half_tiles; int reverse; };
 int launch_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, void* C,
                      int ldc, int M, int N, int K, int epi, hipStream_t st, GemmBf16Info* info = nullptr, const BfEpiLn* ln = nullptr,
                      int f16 = 0);   // f16 != 0: _Float16 operands / outputs (persistent kernel, epilogues 3 / 4 / 5, and 6 = fp32 output)

@@ -675,7 +675,8 @@ int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int 
         const BfEpiLn f1{p.rowstat, h->p16_vec(l, 2), nullptr, nullptr, nullptr};
         PROF(PC_GEMM, launch_gemm_bf16(xo, C, h->p16_w(4 * l + 2), C, h->p16_vec(l, 3), nullptr, p.hid, F, M, F, C, 4, st, nullptr, &f1, 1));
         const BfEpiLn f2{p.ident, nullptr, id_g, id_b, last ? nullptr : p.stats_part};
-        PROF(PC_GEMM, launch_gemm_bf16(p.hid, F, h->p16_w(4 * l + 3), F, h->lw(l, L_FC2B), xo, xc, C, M, C, F, 5, st, nullptr, &f2, 1));
+        GemmBf16Info rv{0, 0, 1};                            // reads FC1's big output: walk the tiles backwards (bf16.hip)
+        PROF(PC_GEMM, launch_gemm_bf16(p.hid, F, h->p16_w(4 * l + 3), F, h->lw(l, L_FC2B), xo, xc, C, M, C, F, 5, st, &rv, &f2, 1));
         if (!last) PROF(PC_ROWOP, launch_ln_rowstat(p.stats_part, p.rowstat, M, npart, C, c.ln_eps, st));
     }
     if (logits_out)

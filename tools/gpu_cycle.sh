@@ -33,6 +33,9 @@ for s in $STEPS; do
     stamps)    run stamps 300 python3 tools/gemm_bf16_stamps.py || exit 1 ;;
     attnctx)   rm -rf /tmp/ac_$TAG; run attnctx 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/ac_$TAG -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 || exit 1
                f=$(find /tmp/ac_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/attn_vs_ctx.py $f > $OUT/attn_vs_ctx.txt && python3 tools/kernels_vs_ctx.py $f > $OUT/kernels_vs_ctx.txt; head -30 $OUT/attn_vs_ctx.txt ;;
+    bertrev)   run bertrev 300 python3 tools/bert_ab.py bf16_gemm_reverse 0 1 || exit 1 ;;
+    berttrace) rm -rf /tmp/bt_$TAG; run berttrace 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bt_$TAG -- python3 tools/bert_prof.py bf16 || exit 1
+               f=$(find /tmp/bt_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/bert_layer_times.py $f > $OUT/bert_layer_times.txt; cat $OUT/bert_layer_times.txt | head -70 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
