@@ -1585,8 +1585,9 @@ int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int
 __global__ __launch_bounds__(256) void dec_embed_f16_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
                                                            const int32_t* __restrict__ ctx_len, const float* __restrict__ tok_emb,
                                                            const float* __restrict__ pos_emb, _Float16* __restrict__ x,
-                                                           float* __restrict__ rowstat, float eps, int M, int T, int C, int vocab,
-                                                           int pos_rows, int absolute_pos, int32_t* __restrict__ err_flag) {
+                                                           float* __restrict__ rowstat, int32_t* __restrict__ mask_out, float eps, int M,
+                                                           int T, int C, int vocab, int pos_rows, int absolute_pos,
+                                                           int32_t* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -1624,25 +1625,27 @@ __global__ __launch_bounds__(256) void dec_embed_f16_kernel(const int32_t* __res
             q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }
     const float var = wave_sum(q) / (float)C;
-    if (lane == 0) *reinterpret_cast<float2*>(rowstat + m * 2) = real ? make_float2(mean, 1.0f / sqrtf(var + eps)) : make_float2(0.f, 1.f);
+    if (lane == 0) {
+        *reinterpret_cast<float2*>(rowstat + m * 2) = real ? make_float2(mean, 1.0f / sqrtf(var + eps)) : make_float2(0.f, 1.f);
+        if (mask_out) mask_out[m] = real ? 1 : 0;           // the key validity the dense attention wants for ragged prompts
+    }
 }
 int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,
-                         void* x, float* rowstat, float eps, int B, int T, int C, int vocab, int pos_rows, int absolute_pos,
+                         void* x, float* rowstat, int32_t* mask_out, float eps, int B, int T, int C, int vocab, int pos_rows, int absolute_pos,
                          int32_t* err_flag, hipStream_t st) {
     MGEA_REQUIRE(C % 4 == 0 && C <= 2048, MGEA_EINVAL, "fp16 embed: d_model=%d must be a multiple of 4 and <= 2048", C);
     hipLaunchKernelGGL(dec_embed_f16_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, st, ids, lens, ctx_len, tok_emb, pos_emb,
-                       (_Float16*)x, rowstat, eps, B * T, T, C, vocab, pos_rows, absolute_pos, err_flag);
+                       (_Float16*)x, rowstat, mask_out, eps, B * T, T, C, vocab, pos_rows, absolute_pos, err_flag);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
 
 // K | V columns of the fp16 qkv rows [M, 3C] -> the fp16 KV pages of `layer` (common.h: K [dh/8][64 tokens][8], V [64 tokens][dh]):
-// one thread per 16-byte group, real tokens only, position ctx_len[b] + t.  mask_out (or nullptr) receives the [B, T] key validity the
-// dense attention wants for ragged prompts.
+// one thread per 16-byte group, real tokens only, position ctx_len[b] + t.
 __global__ __launch_bounds__(256) void kv_scatter_f16_kernel(const _Float16* __restrict__ qkv, KvPool pool, int layer,
                                                             const int32_t* __restrict__ page_table, int max_pages,
                                                             const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ lens,
-                                                            int32_t* __restrict__ mask_out, int64_t n_groups, int T, int C) {
+                                                            int64_t n_groups, int T, int C) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= n_groups) return;
     const int gpr = (2 * C) >> 3;                       // 16-byte groups of K | V per row
@@ -1650,7 +1653,6 @@ __global__ __launch_bounds__(256) void kv_scatter_f16_kernel(const _Float16* __r
     const int gi = (int)(gid - m * gpr);
     const int b = (int)(m / T), t = (int)(m % T);
     const bool real = lens ? (t < lens[b]) : true;
-    if (mask_out && gi == 0) mask_out[m] = real ? 1 : 0;
     if (!real) return;
     const int pos = ctx_len[b] + t;
     const int page = pos >> 6, slot = pos & 63;
@@ -1664,11 +1666,11 @@ __global__ __launch_bounds__(256) void kv_scatter_f16_kernel(const _Float16* __r
     *reinterpret_cast<float4*>(pg + (isv ? slot * pool.dh + d : ((d >> 3) * MGEA_KV_PAGE_TOKENS + slot) * 8)) = raw;
 }
 int launch_kv_scatter_f16(const void* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages, const int32_t* ctx_len,
-                          const int32_t* lens, int32_t* mask_out, int B, int T, int C, hipStream_t st) {
+                          const int32_t* lens, int B, int T, int C, hipStream_t st) {
     MGEA_REQUIRE(pool.f16 && pool.dh % 8 == 0 && C % 8 == 0, MGEA_EINVAL, "fp16 KV scatter needs fp16 pages and head_dim %% 8 == 0");
     const int64_t n_groups = (int64_t)B * T * ((2 * C) >> 3);
     hipLaunchKernelGGL(kv_scatter_f16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, (const _Float16*)qkv, pool, layer,
-                       page_table, max_pages, ctx_len, lens, mask_out, n_groups, T, C);
+                       page_table, max_pages, ctx_len, lens, n_groups, T, C);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

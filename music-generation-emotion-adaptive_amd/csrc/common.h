@@ -46,6 +46,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
+       TUNE_DECODER_PREFILL16_OVERLAP,   // 1 (default): the KV scatter of the fp16 prefill runs on a side stream under the attention kernel
        TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
                                   // fills the chip (default), 2 whenever the kernels accept the shape (tests)
        TUNE_COUNT };
@@ -250,10 +251,10 @@ int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int
 
 // fp16 big-batch prefill of the decoder (bf16.hip): embedding rows as fp16 + their (mean, rstd); K | V of fp16 qkv rows -> fp16 KV pages
 int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,
-                         void* x, float* rowstat, float eps, int B, int T, int C, int vocab, int pos_rows, int absolute_pos,
-                         int32_t* err_flag, hipStream_t st);
+                         void* x, float* rowstat, int32_t* mask_out, float eps, int B, int T, int C, int vocab, int pos_rows,
+                         int absolute_pos, int32_t* err_flag, hipStream_t st);
 int launch_kv_scatter_f16(const void* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages, const int32_t* ctx_len,
-                          const int32_t* lens, int32_t* mask_out, int B, int T, int C, hipStream_t st);
+                          const int32_t* lens, int B, int T, int C, hipStream_t st);
 
 // ---- fused skinny GEMM (decode step, M <= MGEA_FUSED_MAX_ROWS): gemm_skinny.hip --------------------------------
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_ACT = 2, EPI_LOGITS = 3 };
