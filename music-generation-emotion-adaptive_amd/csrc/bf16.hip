@@ -1303,16 +1303,21 @@ __device__ __forceinline__ float quad_max(float x) {
 // S^T = K Q^T keeps a query's scores lane-local (lane = query, registers = keys 16 kt + 4 g + r); the k index of the P V product is
 // permuted to match (k = 8 g + j  <->  key 32 p + 16 (j >> 2) + 4 g + (j & 3)), so P goes from accumulator to operand in registers.
 // The output tile goes through the (then free) K image so that every store instruction writes complete 128-byte rows.
-template <typename E>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NW waves x 32 queries per workgroup, keys staged KB = 32 NW at a time: <4, 128> (two workgroups per CU) for short sequences -- DistilBERT: K and V
+// of a (batch, head) leave HBM exactly once --, <8, 256> (one workgroup per CU, 2 x 64 KB stages) for long ones, where the per-unit costs (the
+// wait for the DMA, the barrier, 8 LDS-DMA pieces per wave: 1.7 of 4.3 us per unit by in-kernel stamps at 1024 keys) are spread over four
+// 64-key tiles instead of two.
+template <typename E, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mask, E* __restrict__ out, int T, int H,
                       int n_items, int nqb, float scale) {
     typedef typename X16<E>::v8 bf16x8;   // (the names below were written for bf16; E may be _Float16)
     typedef typename X16<E>::v4 bf16x4;
     typedef E bf16_t;
-    constexpr int DH = 64, KB = 128;
-    constexpr int STAGE = 2048;                                   // 16-byte chunks: K image, then V image
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE], then [2][2] 64-bit validity words
+    constexpr int DH = 64, KB = 32 * NW, QPB = 32 * NW;           // keys per stage, queries per workgroup
+    constexpr int STAGE = KB * 16;                                // 16-byte chunks: K image [KB][8], then V image [KB][8]
+    constexpr int VW = KB / 64;                                   // 64-bit validity words per stage
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];  // [2][STAGE], then [2][VW] 64-bit validity words
     unsigned long long* sValid = reinterpret_cast<unsigned long long*>(lds + 2 * STAGE);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
 
@@ -1338,10 +1343,10 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
             const unsigned row = (unsigned)kr * (unsigned)(6 * C);    // bytes; a sequence's rows span < 4 GB (checked on the host)
             const unsigned dst = lds_base + (unsigned)(st * STAGE + piece * 64) * 16u;
             glds16_hidden_s(base, row + dk_off, dst);
-            glds16_hidden_s(base, row + dv_off, dst + 1024u * 16u);
+            glds16_hidden_s(base, row + dv_off, dst + (unsigned)(KB * 8) * 16u);
         }
     };
-    auto mask_of = [&](int it, int kbi) -> int {                  // validity of key kbi * 128 + tid (waves 0 and 1)
+    auto mask_of = [&](int it, int kbi) -> int {                  // validity of key kbi * KB + tid (the first KB / 64 waves)
         const int bh = it / nqb, bb = bh / H;
         const int kidx = kbi * KB + tid;
         int ok = (tid < KB && kidx < T) ? 1 : 0;
@@ -1353,7 +1358,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
         const int bh = it / nqb, qb = it - bh * nqb, bb = bh / H, hh = bh - bb * H;
 #pragma unroll
         for (int mq = 0; mq < 2; ++mq) {
-            int qr = qb * 128 + wave * 32 + mq * 16 + c; qr = qr < T ? qr : T - 1;
+            int qr = qb * QPB + wave * 32 + mq * 16 + c; qr = qr < T ? qr : T - 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 qn[mq][ks] = *reinterpret_cast<const bf16x8*>(qkv + ((int64_t)bb * T + qr) * 3 * C + hh * DH + ks * 32 + 8 * g);
@@ -1390,18 +1395,22 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    int un = 0;                                                    // (tools-only stamps: unit counter)
     while (item < n_items) {
+        PH_STAMP(un * 8 + 0);
         // unit (item, kb) has landed: nothing younger than its DMA, its mask word and (kb == 0) its Q rows is in flight here
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PH_STAMP(un * 8 + 1);
         // Tell hipcc that the prefetched registers are complete on every path.  It does not read the wait above, and a load it still
         // believes pending makes it wait (by ITS count, which does not include the hidden DMAs: in effect vmcnt(0)) before those
         // registers are written again -- right after the next unit's DMA was issued, which would serialise the pipeline.
         asm volatile("" : "+v"(qn[0][0]), "+v"(qn[0][1]), "+v"(qn[1][0]), "+v"(qn[1][1]), "+v"(mk));
         if (tid < KB) {
             const unsigned long long bal = __ballot(mk != 0);
-            if (lane == 0) sValid[stage * 2 + wave] = bal;
+            if (lane == 0) sValid[stage * VW + wave] = bal;
         }
         __syncthreads();
+        PH_STAMP(un * 8 + 2);
         if (kb == 0) {
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq) {
@@ -1422,12 +1431,13 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
         }
         MGEA_FLUSH_OUT();
         optr = nullptr;
+        PH_STAMP(un * 8 + 3);
 
         const float4* sK = lds + stage * STAGE;
-        const bf16_t* sV = reinterpret_cast<const bf16_t*>(lds + stage * STAGE + 1024);
+        const bf16_t* sV = reinterpret_cast<const bf16_t*>(lds + stage * STAGE + KB * 8);
 #pragma unroll 1
         for (int t0 = 0; t0 < KB && kb * KB + t0 < T; t0 += 64) {   // workgroup-uniform bounds
-            const unsigned long long vm = sValid[stage * 2 + (t0 >> 6)];
+            const unsigned long long vm = sValid[stage * VW + (t0 >> 6)];
             const unsigned vm_lo = __builtin_amdgcn_readfirstlane((unsigned)vm), vm_hi = __builtin_amdgcn_readfirstlane((unsigned)(vm >> 32));
             const bool all_valid = (vm_lo & vm_hi) == 0xffffffffu;                         // wave-uniform
             const unsigned vb_lo = vm_lo >> (4 * g), vb_hi = vm_hi >> (4 * g);              // bit 16 (kt & 1) + r of word kt >> 1
@@ -1514,6 +1524,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 }
         }
 
+        PH_STAMP(un * 8 + 4);
         if (kb == nkb - 1) {
             const int bh = item / nqb, qb = item - bh * nqb, bb = bh / H, hh = bh - bb * H;
             __syncthreads();                                      // every wave is done with this stage's K image
@@ -1542,39 +1553,45 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 ov2 = *reinterpret_cast<const float4*>(sp + 16 * 64);
                 ov3 = *reinterpret_cast<const float4*>(sp + 24 * 64);
             }
-            orow = qb * 128 + wave * 32 + (lane >> 3);
+            orow = qb * QPB + wave * 32 + (lane >> 3);
             optr = out + ((int64_t)bb * T + orow) * C + hh * DH + (lane & 7) * 8;
         }
         item = nitem; kb = nkbi; stage ^= 1;
+        PH_STAMP(un * 8 + 5);
+        ++un;
     }
     MGEA_FLUSH_OUT();
 #undef MGEA_FLUSH_OUT
 }
 
+template <typename E, int NW>
+static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, hipStream_t st) {
+    constexpr int QPB = 32 * NW, KB = 32 * NW;
+    const int nqb = ceil_div(T, QPB);
+    const int64_t n_items = (int64_t)B * H * nqb;
+    MGEA_REQUIRE(n_items < (1 << 30), MGEA_EINVAL, "16-bit attention: too many (batch, head, query block) items");
+    DeviceInfo di;
+    MGEA_TRY(device_info(&di));
+    const int shmem = 2 * KB * 16 * 16 + 64;
+    static uint64_t attr_done = 0;                     // per instantiation
+    MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<E, NW>, shmem, di.dev, &attr_done));
+    const int per_cu = NW == 4 ? 2 : 1;
+    const int grid = (int)(n_items < per_cu * di.n_cu ? n_items : per_cu * di.n_cu);
+    hipLaunchKernelGGL((attn_bf16_kernel<E, NW>), dim3(grid), dim3(64 * NW), shmem, st, (const E*)qkv, mask, (E*)out, T, H, (int)n_items, nqb,
+                       0.125f);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
 int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16) {
     MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
-    const int nqb = ceil_div(T, 128);
-    const int64_t n_items = (int64_t)B * H * nqb;
-    MGEA_REQUIRE(n_items < (1 << 30), MGEA_EINVAL, "bf16 attention: too many (batch, head, query block) items");
     MGEA_REQUIRE((int64_t)T * 6 * H * dh < ((int64_t)1 << 32), MGEA_EINVAL, "bf16 attention: one sequence of qkv rows must span < 4 GB");
-    DeviceInfo di;
-    MGEA_TRY(device_info(&di));
-    const int n_cu = di.n_cu;
-    const int shmem = 2 * 2048 * 16 + 64;
-    static uint64_t attr_done = 0;
-    static uint64_t attr_done_h = 0;
-    if (f16) MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<_Float16>, shmem, di.dev, &attr_done_h));
-    else     MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<bf16_t>, shmem, di.dev, &attr_done));
-    const int grid = (int)(n_items < 2 * n_cu ? n_items : 2 * n_cu);
-    if (f16)
-        hipLaunchKernelGGL(attn_bf16_kernel<_Float16>, dim3(grid), dim3(256), shmem, st, (const _Float16*)qkv, mask, (_Float16*)out, T, H,
-                           (int)n_items, nqb, 1.0f / sqrtf((float)dh));
-    else
-        hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, dim3(grid), dim3(256), shmem, st, (const bf16_t*)qkv, mask, (bf16_t*)out, T, H,
-                           (int)n_items, nqb, 1.0f / sqrtf((float)dh));
-    MGEA_CHECK_HIP(hipGetLastError());
-    return MGEA_OK;
+    // long sequences: 256 queries / 256 keys per unit (switch attn16_wide: 0 never, 1 from 512 tokens (default), 2 always)
+    const int wide = tune(TUNE_ATTN16_WIDE);
+    const bool w8 = wide == 2 || (wide == 1 && T >= 512);
+    if (f16) return w8 ? launch_attn16<_Float16, 8>(qkv, mask, out, B, T, H, st) : launch_attn16<_Float16, 4>(qkv, mask, out, B, T, H, st);
+    return w8 ? launch_attn16<bf16_t, 8>(qkv, mask, out, B, T, H, st) : launch_attn16<bf16_t, 4>(qkv, mask, out, B, T, H, st);
 }
 
 // ------------------------------------------------------------------------------------------

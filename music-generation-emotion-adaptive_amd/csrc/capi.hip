@@ -27,7 +27,8 @@ const TuneEntry kTune[TUNE_COUNT] = {
     {"bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},     {"bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
     {"bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
     {"decoder_unfused", "MGEA_DECODER_UNFUSED", 0},   {"decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
-    {"decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},   {"decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
+    {"decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},   {"attn16_wide", "MGEA_ATTN16_WIDE", 1},
+    {"decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
     {"decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
 };
 std::atomic<int> g_tune[TUNE_COUNT];

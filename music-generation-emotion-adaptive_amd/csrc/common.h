@@ -46,6 +46,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
+       TUNE_ATTN16_WIDE,          // 16-bit flash attention with 8 waves / 256-key stages: 0 never, 1 from 512 tokens on (default), 2 always
        TUNE_DECODER_PREFILL16_OVERLAP,   // 1 (default): the KV scatter of the fp16 prefill runs on a side stream under the attention kernel
        TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
                                   // fills the chip (default), 2 whenever the kernels accept the shape (tests)

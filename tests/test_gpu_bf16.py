@@ -216,10 +216,14 @@ def test_layernorm_bf16():
     assert float((got.double() - want).abs().max()) < 3e-2
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 128, 12), (3, 24, 2), (1, 200, 4), (2, 64, 8), (1, 1, 1), (2, 129, 3), (5, 513, 1)])
+@pytest.mark.parametrize("B,T,H", [(2, 128, 12), (3, 24, 2), (1, 200, 4), (2, 64, 8), (1, 1, 1), (2, 129, 3), (5, 513, 1), (2, 1024, 2)])
 @pytest.mark.parametrize("masked", [False, True])
-def test_attention_bf16(B, T, H, masked):
+@pytest.mark.parametrize("wide", [0, 2])
+def test_attention_bf16(B, T, H, masked, wide, tune):
+    """wide: the 4-wave / 128-key form (two workgroups per CU) and the 8-wave / 256-key form the launcher picks from 512 tokens on,
+    each forced on every shape (switch attn16_wide)."""
     from mgea import ops
+    tune("attn16_wide", wide)
     dh, C = 64, H * 64
     qkv = rnd(B, T, 3 * C, seed=7, scale=1.5).bfloat16()
     valid = torch.ones(B, T, dtype=torch.bool)
@@ -241,12 +245,14 @@ def _attention_ref(qkv, H, valid):
     return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, C)
 
 
-def test_attention_bf16_persistent_walk_and_rescale_paths():
+@pytest.mark.parametrize("wide", [0, 2])
+def test_attention_bf16_persistent_walk_and_rescale_paths(wide, tune):
     """The kernel is persistent (2 workgroups per CU walk the (batch, head, query block) items through two LDS stages) and rescales
     its accumulators only when a row's maximum outgrows the reference by 2^16: cover (a) more items than workgroups, (b) several
     key blocks and query blocks per sequence, (c) a later key tile whose scores dwarf the earlier ones (the rescale path),
     (d) a first key tile that is masked out completely (rows with no valid key until the second tile)."""
     from mgea import ops
+    tune("attn16_wide", wide)
     # (a) 1152 items on at most 512 workgroups
     B, T, H = 96, 64, 12
     qkv = rnd(B, T, 3 * H * 64, seed=11, scale=1.5).bfloat16()

@@ -37,6 +37,8 @@ for s in $STEPS; do
     berttrace) rm -rf /tmp/bt_$TAG; run berttrace 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bt_$TAG -- python3 tools/bert_prof.py bf16 || exit 1
                f=$(find /tmp/bt_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/bert_layer_times.py $f > $OUT/bert_layer_times.txt; cat $OUT/bert_layer_times.txt | head -70 ;;
     prefillab) run prefillab 300 python3 tools/prefill_ab.py decoder_prefill16_overlap 0 1 || exit 1 ;;
+    attnwide)  run attnwide 300 python3 tools/prefill_ab.py attn16_wide 0 1 || exit 1 ;;
+    attnstamps) run attnstamps 300 python3 tools/attn_stamps.py || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
