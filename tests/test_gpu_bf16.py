@@ -156,6 +156,32 @@ def test_gemm_bf16_bench_shape_every_epilogue_and_tail_schedule(N, K, epi, tune)
         assert float((rs[:, 1].double() * xd.var(1, unbiased=False).sqrt() - 1.0).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 192), (12288, 2048, 320), (8448, 2304, 448), (16384, 768, 64), (5000, 4096, 192)])
+@pytest.mark.parametrize("epi", [0, 2, 5])
+def test_gemm_bf16_stream_across_tiles_with_odd_k_tiles(M, N, K, epi, tune):
+    """Several whole tiles per workgroup with an ODD number of K-tiles (3, 5, 7) and with a single one: between two whole tiles the
+    LDS-DMA stream continues over the boundary and the stage a K-tile lands in alternates with the running parity (sb), which the
+    DistilBERT shapes (12 / 48 K-tiles) never toggle; 8448 x 2304 also ends in half-tile units (297 tiles on 256 workgroups), and
+    M = 5000 has a ragged last row tile.  Every element against fp32 math on the same inputs, twice, all three tail schedules
+    bitwise equal."""
+    from mgea import ops
+    tune("bf16_gemm_tile", 4)
+    a, w, b, (want, scale), kw = _gemm_case(M, N, K, epi, seed=51)
+    first = None
+    for tail in (2, 0, 1):
+        tune("bf16_gemm_tail", tail)
+        for _ in range(2):
+            info = []
+            got = ops.gemm_bf16(a, w, b, info=info, **kw)
+            assert info[0] == 2
+            out = got[0] if epi == 5 else got
+            if first is None:
+                first = out
+                assert float(((out.float() - want).abs() / scale).max()) < BF16_REL
+            else:
+                assert torch.equal(out, first)
+
+
 def test_gemm_bf16_row_statistics_of_offset_rows():
     """Rows whose mean is far from zero against their spread (outlier hidden dimensions of trained checkpoints; synthetic weights
     never produce them): epilogue 5 leaves (sum, M2 about the TILE mean) per tile and ln_rowstat merges the tiles exactly, so the
