@@ -410,11 +410,27 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 __device__ unsigned long long* g_ph_stamps = nullptr;      // [workgroup][64] 100 MHz ticks, written by thread 0
 #define PH_STAMP(i) do { if (g_ph_stamps && tid == 0 && (i) < 64) g_ph_stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int mgea_dbg_set_ph_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamps), &p, sizeof(p)); }
+// ablation (wrong results, tools-only build): every unit loads tile 0's operands -- 192 KB of A and W that never leave L2 -- to
+// tell a K loop bound by operand DELIVERY (it speeds up) from one bound by instruction issue (it does not)
+__device__ int g_ph_same_tile = 0;
+extern "C" int mgea_dbg_set_ph_same_tile(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ph_same_tile), &v, sizeof(v)); }
+#define PH_TILE_FOR_LOADS(t) (g_ph_same_tile ? 0 : (t))
+// more timing ablations of the whole-tile K loop (wrong results), chosen at COMPILE time (-DMGEA_PH_ABLATE=bits: a run-time test around
+// the reads or the MFMAs changes the loop it is meant to measure -- it tripled it): bit 0 no LDS-DMA after the prologue, bit 1 no fragment
+// reads, bit 2 no MFMAs
+#ifndef MGEA_PH_ABLATE
+#define MGEA_PH_ABLATE 0
+#endif
+#define PH_ABLATE_INIT
+#define PH_ABLATE(bit) (((MGEA_PH_ABLATE) >> (bit)) & 1)
 #else
+#define PH_ABLATE_INIT
+#define PH_ABLATE(bit) 0
 #define PH_STAMP(i) do { } while (0)
+#define PH_TILE_FOR_LOADS(t) (t)
 #endif
 
-template <int EPI, typename T>
+template <int EPI, typename T, bool PH2>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
                                                           T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
@@ -434,6 +450,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     const int wm = wave >> 2, wn = wave & 3;               // wm = 1: the late group
     const int KT = K >> 6;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;   // LDS byte address of the ring
+    PH_ABLATE_INIT
 
     // PERSISTENT: one workgroup per CU walks its output tiles.  Workgroups b and b + 8 share an XCD (round-robin dispatch, speed
     // only): XCD r = b % 8 gets the contiguous run of tiles [r * n_tiles / 8, (r + 1) * n_tiles / 8) so that the tiles in flight on
@@ -482,28 +499,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // LDS-DMA sources: a half-tile = 128 rows x 128 B = 16 pieces of 8 rows; wave w moves pieces 2w, 2w+1 of every half-tile.
     // The LDS image is lane-linear, so the XOR swizzle sits on the SOURCE chunk (lane -> row lane/8, chunk (lane%8) ^ (row%8)).
     const int lr = lane >> 3, lch = (lane & 7) ^ lr;
-    const T* src[4][2];     // [half-tile: A0, A1, W0, W1][piece]
+    // A piece's source = a wave-uniform 64-bit base in SGPRs (the unit's first A / W row, advanced by 128 bytes per K-tile with scalar
+    // adds) + a 32-bit byte offset per lane (row inside the unit, clamped to the matrix, and the swizzled chunk): no vector
+    // arithmetic per piece.  (Round 2 kept 8 full pointers per lane and added kt * 128 to one for every piece: two 64-bit VALU adds
+    // per piece in the L-segments, whose instruction count is what the K loop is bound by -- beside the partner wave's MFMAs an
+    // L-segment gets about one issue slot per MFMA.)
+    unsigned voff[4][2];     // [half-tile: A0, A1, W0, W1][piece]
+    const char *abase = nullptr, *wbase = nullptr;
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int t, int md) {                    // md != 0: the 128 rows of that half sit in rows 0..127 of the A stage
         m0 = (t / tiles_n) * BM + (md == 2 ? 128 : 0); n0 = (t % tiles_n) * BN;
+        const int lt = PH_TILE_FOR_LOADS(t), lm0 = (lt / tiles_n) * BM + (md == 2 ? 128 : 0), ln0 = (lt % tiles_n) * BN;   // (= m0, n0 in the product build)
+        abase = reinterpret_cast<const char*>(A + (int64_t)lm0 * lda);
+        wbase = reinterpret_cast<const char*>(W + (int64_t)ln0 * ldw);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int ra = m0 + hf * 128 + (wave * 2 + i) * 8 + lr;
-                ra = ra < M ? ra : M - 1;
-                src[hf][i] = A + (int64_t)ra * lda + lch * 8;
-                int rw = n0 + hf * 128 + (wave * 2 + i) * 8 + lr;
-                rw = rw < N ? rw : N - 1;
-                src[2 + hf][i] = W + (int64_t)rw * ldw + lch * 8;
+                int ra = hf * 128 + (wave * 2 + i) * 8 + lr;          // row inside the unit; the unit's first row is inside the matrix
+                ra = lm0 + ra < M ? ra : M - 1 - lm0;
+                voff[hf][i] = (unsigned)(ra * lda + lch * 8) * 2u;
+                int rw = hf * 128 + (wave * 2 + i) * 8 + lr;
+                rw = ln0 + rw < N ? rw : N - 1 - ln0;
+                voff[2 + hf][i] = (unsigned)(rw * ldw + lch * 8) * 2u;
             }
     };
     auto issue_half = [&](int hid, int kt, int stage) {   // hid: 0 A rows 0..127, 1 A rows 128..255, 2 W rows 0..127, 3 W rows 128..255
+        const char* base = (hid >= 2 ? wbase : abase) + kt * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
             const unsigned dst = lds_base + (unsigned)(stage * STAGE + (hid >= 2 ? SA : 0) + row0 * 8) * 16u;
-            glds16_hidden(src[hid][i] + kt * 64, dst);
+            glds16_hidden_s(base, voff[hid][i], dst);
         }
     };
     // HALF UNITS (128 x 256 of C, mode 1 / 2) have their own K loop: a K-tile is A 128 rows (16 KB) + W 256 rows (32 KB) = 48 KB, so
@@ -526,7 +553,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         for (int i = 0; i < 2; ++i) {
             const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
             const unsigned dst = lds_base + (unsigned)(st3 * HSTAGE + (hid >= 2 ? HSA : 0) + row0 * 8) * 16u;
-            glds16_hidden(src[hid][i] + kt * 64, dst);
+            glds16_hidden_s((hid >= 2 ? wbase : abase) + kt * 128, voff[hid][i], dst);
         }
     };
     // whole tiles: tile 0 whole, then W0 / A0 / A1 of tile 1 (the steady state issues W0 and A0 + A1 of K-tile u+2 in phases 4u+2
@@ -534,7 +561,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     auto issue_prologue = [&](int nkt, int md) {
         if (md == 0) {
             issue_half(2, 0, 0); issue_half(0, 0, 0); issue_half(3, 0, 0); issue_half(1, 0, 0);
-            if (nkt > 1) { issue_half(2, 1, 1); issue_half(0, 1, 1); issue_half(1, 1, 1); }
+            if (nkt > 1) {
+                if (PH2) { issue_half(2, 1, 1); issue_half(3, 1, 1); }                            // two-phase loop: W of K-tile 1
+                else     { issue_half(2, 1, 1); issue_half(0, 1, 1); issue_half(1, 1, 1); }
+            }
         } else {
             issue_h(2, 0, 0); issue_h(0, 0, 0); issue_h(3, 0, 0);
             if (nkt > 1) { issue_h(2, 1, 1); issue_h(0, 1, 1); issue_h(3, 1, 1); }
@@ -571,7 +601,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         // unit's) are still in flight.  (After the first unit the previous epilogue's stores are younger than these DMAs and count too: the
         // wait is then stronger, never weaker.)
         if (nkt > 1) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (PH2 && !halfu) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else               asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -580,7 +611,80 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         PH_STAMP(sbase + 1);                                // K-tile 0 landed, K loop starts
 
         v8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
-        if (!halfu) {
+        if (!halfu && PH2) {
+        // TWO phases of 32 MFMAs per K-tile (switch bf16_gemm_phases = 2).  Compile-time ablations of the four-phase loop
+        // (tools/gemm_bf16_ablate.sh) put the skeleton of a K-tile -- 8 barrier-to-barrier intervals with their reads and DMAs but
+        // no MFMA -- at 0.89 us and its 64 MFMAs per wave at 1.0 us of matrix pipe for the SIMD's two waves, yet the loop takes 1.6 us:
+        // every interval pays ~130 cycles of barrier turn-around on top of its 256 MFMA cycles.  Here a K-tile has 4 intervals of 512:
+        //   reads : P0 reads W(j=0), W(j=1) and A(i=0) (16 ds_read_b128), P1 reads A(i=1) (8); the W fragments stay in registers.
+        //           W of stage u & 1 is last read in interval 2(2u)+1 = 4u+1, A in interval 2(2u+1)+1 = 4u+3.
+        //   WAR   : W0 / W1 of K-tile u+2 (same stage) are issued in phase 2u+1 (first interval 4u+2 > 4u+1), A0 / A1 of K-tile u+1
+        //           (stage (u+1) & 1, last read in interval 4(u-1)+3 = 4u-1) in phase 2u (first interval 4u).
+        //   RAW   : K-tile u+1 is first read in interval 4u+4; its W was issued in phase 2u-1, its A in phase 2u; every wave waits
+        //           for ITS pieces at the end of interval 4u+3 (early: end of C(2u+1), late: end of L(2u+1)) with vmcnt(4) -- only
+        //           the two W halves of K-tile u+2, issued in phase 2u+1, may still be in flight.
+        // A gets 4 intervals (~2500 cycles) of lookahead instead of 10 x 390; W, the L2-resident operand, 6.
+        for (int u = 0; u < nkt; ++u) {
+            const float4* sbuf = lds + ((u + sb) & 1) * STAGE;
+            const float4* sa = sbuf + (wm * 128) * 8;
+            const float4* sw = sbuf + SA + (wn * 64) * 8;
+            const int g1 = u + 1, g2 = u + 2;               // K-tiles the DMAs of this K-tile belong to (>= nkt: the next unit's)
+            const bool i1 = g1 < nkt || stream, i2 = g2 < nkt || stream;
+            const int k1 = g1 < nkt ? g1 : g1 - nkt, k2 = g2 < nkt ? g2 : g2 - nkt;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // ---------------- L-segment
+                if (p == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) {
+                                const float4 v = sw[((j * 2 + n) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                                if (j == 0) bf0[n][ks] = *reinterpret_cast<const v8*>(&v);
+                                else        bf1[n][ks] = *reinterpret_cast<const v8*>(&v);
+                            }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)      // A fragments of the 64-row half i = p
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float4 v = sa[((p * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+                        af[m][ks] = *reinterpret_cast<const v8*>(&v);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (p == 0 && i1) { issue_half(0, k1, (g1 + sb) & 1); issue_half(1, k1, (g1 + sb) & 1); }
+                if (p == 1 && stream && u == nkt - 2) set_tile(nx_tile, 0);   // this unit's last DMA is out: the next unit's addresses
+                if (p == 1 && i2) { issue_half(2, k2, (g2 + sb) & 1); issue_half(3, k2, (g2 + sb) & 1); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
+                if (p == 1 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(2u+1) ...
+                    if (i2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- C-segment: quadrants (i = p, j = 0) and (i = p, j = 1)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            acc[n][p * 4 + m] = X16<T>::mfma(bf0[n][ks], af[m][ks], acc[n][p * 4 + m]);
+                            acc[2 + n][p * 4 + m] = X16<T>::mfma(bf1[n][ks], af[m][ks], acc[2 + n][p * 4 + m]);
+                        }
+                __builtin_amdgcn_s_setprio(0);
+                if (p == 1 && wm == 0) {     // ... the early group at the end of its C(2u+1): the same interval
+                    if (i2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        } else if (!halfu) {
         for (int u = 0; u < nkt; ++u) {
             const float4* sbuf = lds + ((u + sb) & 1) * STAGE;
             const float4* sa = sbuf + (wm * 128) * 8;
@@ -591,7 +695,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // ---------------- L-segment
-                if (p == 0 || p == 1) {      // W fragments of the 32-column half j = p
+                if ((p == 0 || p == 1) && !PH_ABLATE(1)) {      // W fragments of the 32-column half j = p
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -601,7 +705,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                             else        bf1[n][ks] = *reinterpret_cast<const v8*>(&v);
                         }
                 }
-                if (p == 0 || p == 2) {      // A fragments of the 64-row half i = p / 2
+                if ((p == 0 || p == 2) && !PH_ABLATE(1)) {      // A fragments of the 64-row half i = p / 2
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -611,10 +715,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!PH_ABLATE(0)) {
                 if (p == 0 && i1) issue_half(3, k1, (g1 + sb) & 1);
                 if (p == 1 && stream && u == nkt - 2) set_tile(nx_tile, 0);   // this unit's last DMA is out: the next unit's addresses
                 if (p == 2 && i2) issue_half(2, k2, (g2 + sb) & 1);
                 if (p == 3 && i2) { issue_half(0, k2, (g2 + sb) & 1); issue_half(1, k2, (g2 + sb) & 1); }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this phase's reads are in registers before anyone may refill
                 if (p == 3 && wm == 1) {     // the late group confirms K-tile u+1 at the end of its L(4u+3) ...
                     if (i2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -624,6 +730,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                 __builtin_amdgcn_s_barrier();
                 // ---------------- C-segment: quadrant (i, j) = (0,0) (0,1) (1,1) (1,0)
                 __builtin_amdgcn_s_setprio(1);
+                if (!PH_ABLATE(2))
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -919,14 +1026,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     }
 }
 
-template <int EPI, typename T = bf16_t>
-static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
-                     int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
+template <int EPI, typename T, bool PH2>
+static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
+                      int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp) {
     const int shmem = 2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     DeviceInfo di;
     MGEA_TRY(device_info(&di));
     static uint64_t attr_done = 0;                      // per instantiation, one bit per device
-    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI, T>), shmem, di.dev, &attr_done));
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI, T, PH2>), shmem, di.dev, &attr_done));
     const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
     const int n_cu = di.n_cu / 8 * 8;
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
@@ -937,10 +1044,16 @@ static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias
         info->kernel = 2;
         info->half_tiles = ((tail & 3) != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
     }
-    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T, PH2>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
                        tail, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
+}
+template <int EPI, typename T = bf16_t>
+static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
+                     int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
+    if (tune(TUNE_BF16_GEMM_PHASES) == 2) return launch_ph2<EPI, T, true>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    return launch_ph2<EPI, T, false>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
 }
 
 template <int EPI, int NT, int WMW>
@@ -1395,7 +1508,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
-    int un = 0;                                                    // (tools-only stamps: unit counter)
+    [[maybe_unused]] int un = 0;                                   // (tools-only stamps: unit counter)
     while (item < n_items) {
         PH_STAMP(un * 8 + 0);
         // unit (item, kb) has landed: nothing younger than its DMA, its mask word and (kb == 0) its Q rows is in flight here

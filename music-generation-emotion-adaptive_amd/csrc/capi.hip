@@ -21,28 +21,35 @@ const char* get_error() { return g_err; }
 
 // ---- switches: one table, initialised from the environment when the library is loaded ---------
 namespace {
-struct TuneEntry { const char* name; const char* env; int dflt; };
-const TuneEntry kTune[TUNE_COUNT] = {
-    {"bf16_gemm_tile", "MGEA_BF16_GEMM_TILE", 0},     {"bf16_gemm_small", "MGEA_BF16_GEMM_SMALL", 0},
-    {"bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},     {"bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
-    {"bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
-    {"decoder_unfused", "MGEA_DECODER_UNFUSED", 0},   {"decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
-    {"decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},   {"attn16_wide", "MGEA_ATTN16_WIDE", 1},
-    {"decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
-    {"decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
+struct TuneEntry { int key; const char* name; const char* env; int dflt; };
+// (each row names its key: the table is looked up by key, never by position)
+const TuneEntry kTune[] = {
+    {TUNE_BF16_GEMM_TILE, "bf16_gemm_tile", "MGEA_BF16_GEMM_TILE", 0},
+    {TUNE_BF16_GEMM_SMALL, "bf16_gemm_small", "MGEA_BF16_GEMM_SMALL", 0},
+    {TUNE_BF16_GEMM_TAIL, "bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},
+    {TUNE_BF16_GEMM_PHASES, "bf16_gemm_phases", "MGEA_BF16_GEMM_PHASES", 4},
+    {TUNE_BF16_GEMM_REVERSE, "bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
+    {TUNE_BERT_BF16_NOFOLD, "bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
+    {TUNE_DECODER_UNFUSED, "decoder_unfused", "MGEA_DECODER_UNFUSED", 0},
+    {TUNE_DECODER_NOGEMV, "decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
+    {TUNE_DECODER_NOGRAPH, "decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},
+    {TUNE_ATTN16_WIDE, "attn16_wide", "MGEA_ATTN16_WIDE", 1},
+    {TUNE_DECODER_PREFILL16_OVERLAP, "decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
+    {TUNE_DECODER_PREFILL16, "decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
 };
+static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];
 struct TuneInit {
     TuneInit() {
-        for (int i = 0; i < TUNE_COUNT; ++i) {
-            const char* e = getenv(kTune[i].env);
-            g_tune[i].store(e && e[0] ? atoi(e) : kTune[i].dflt, std::memory_order_relaxed);
+        for (const TuneEntry& t : kTune) {
+            const char* e = getenv(t.env);
+            g_tune[t.key].store(e && e[0] ? atoi(e) : t.dflt, std::memory_order_relaxed);
         }
     }
 } g_tune_init;
 int tune_index(const char* name) {
-    for (int i = 0; name && i < TUNE_COUNT; ++i)
-        if (!strcmp(name, kTune[i].name)) return i;
+    for (const TuneEntry& t : kTune)
+        if (name && !strcmp(name, t.name)) return t.key;
     return -1;
 }
 }  // namespace

@@ -18,6 +18,15 @@ lib.mgea_dbg_set_ph_stamps.restype = C.c_int
 lib.mgea_dbg_set_ph_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(256, 64, dtype=torch.int64, device="cuda")
 assert lib.mgea_dbg_set_ph_stamps(C.c_void_p(stamps.data_ptr())) == 0
+lib.mgea_dbg_set_ph_same_tile.restype = C.c_int
+lib.mgea_dbg_set_ph_same_tile.argtypes = [C.c_int]
+SAME = len(sys.argv) > 1 and sys.argv[1] == "same_tile"      # ablation: every unit loads tile 0's operands (L2-resident; wrong results)
+assert lib.mgea_dbg_set_ph_same_tile(1 if SAME else 0) == 0
+if "_a" in os.path.basename(os.environ["MGEA_LIB_PATH"]):
+    print(f"ABLATION build {os.path.basename(os.environ['MGEA_LIB_PATH'])} (bits: 1 no LDS-DMA after the prologue, 2 no ds_reads, 4 no MFMAs; whole-tile K loop): "
+          "wrong results, timings only")
+if SAME:
+    print("ABLATION same_tile: every unit loads the operands of tile 0 (they never leave L2); results are wrong, timings only")
 M = 32768
 NAMES = {0: "start", 1: "K0 landed", 2: "K loop done", 3: "next prologue issued"}
 for name, N, K, epi in [("qkv", 2304, 768, 3), ("out", 768, 768, 5), ("fc1", 3072, 768, 4), ("fc2", 768, 3072, 5), ("qkv0", 2304, 768, 0)]:

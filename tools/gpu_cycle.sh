@@ -31,6 +31,7 @@ for s in $STEPS; do
     bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
     f16tests)  run f16tests 600 python3 -m pytest tests/test_gpu_f16.py -x -q -m gpu -s || exit 1 ;;
     stamps)    run stamps 300 python3 tools/gemm_bf16_stamps.py || exit 1 ;;
+    stampsame) run stampsame 300 python3 tools/gemm_bf16_stamps.py same_tile || exit 1 ;;
     attnctx)   rm -rf /tmp/ac_$TAG; run attnctx 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/ac_$TAG -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra --profile-stride 0 || exit 1
                f=$(find /tmp/ac_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/attn_vs_ctx.py $f > $OUT/attn_vs_ctx.txt && python3 tools/kernels_vs_ctx.py $f > $OUT/kernels_vs_ctx.txt; head -30 $OUT/attn_vs_ctx.txt ;;
     bertrev)   run bertrev 300 python3 tools/bert_ab.py bf16_gemm_reverse 0 1 || exit 1 ;;
@@ -39,6 +40,7 @@ for s in $STEPS; do
     prefillab) run prefillab 300 python3 tools/prefill_ab.py decoder_prefill16_overlap 0 1 || exit 1 ;;
     attnwide)  run attnwide 300 python3 tools/prefill_ab.py attn16_wide 0 1 || exit 1 ;;
     attnstamps) run attnstamps 300 python3 tools/attn_stamps.py || exit 1 ;;
+    bertph)    run bertph 300 python3 tools/bert_ab.py bf16_gemm_phases 4 2 || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
