@@ -408,8 +408,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // (tools/build_stamps.sh: -DMGEA_PH_STAMPS, a separate .so that tools/gemm_bf16_stamps.py loads); the product library has none of it.
 #ifdef MGEA_PH_STAMPS
 __device__ unsigned long long* g_ph_stamps = nullptr;      // [workgroup][64] 100 MHz ticks, written by thread 0
-#define PH_STAMP(i) do { if (g_ph_stamps && tid == 0 && (i) < 64) g_ph_stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long* g_ph_cycles = nullptr;      // same slots, shader-clock cycles (s_memtime): cycles / ticks = the clock the loop held
+#define PH_STAMP(i) do { if (g_ph_stamps && tid == 0 && (i) < 64) { g_ph_stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+                                                                    if (g_ph_cycles) g_ph_cycles[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 extern "C" int mgea_dbg_set_ph_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamps), &p, sizeof(p)); }
+extern "C" int mgea_dbg_set_ph_cycles(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ph_cycles), &p, sizeof(p)); }
 // ablation (wrong results, tools-only build): every unit loads tile 0's operands -- 192 KB of A and W that never leave L2 -- to
 // tell a K loop bound by operand DELIVERY (it speeds up) from one bound by instruction issue (it does not)
 __device__ int g_ph_same_tile = 0;
@@ -430,7 +433,7 @@ extern "C" int mgea_dbg_set_ph_same_tile(int v) { return (int)hipMemcpyToSymbol(
 #define PH_TILE_FOR_LOADS(t) (t)
 #endif
 
-template <int EPI, typename T, bool PH2>
+template <int EPI, typename T, int PH>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
                                                           T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles,
@@ -562,8 +565,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         if (md == 0) {
             issue_half(2, 0, 0); issue_half(0, 0, 0); issue_half(3, 0, 0); issue_half(1, 0, 0);
             if (nkt > 1) {
-                if (PH2) { issue_half(2, 1, 1); issue_half(3, 1, 1); }                            // two-phase loop: W of K-tile 1
-                else     { issue_half(2, 1, 1); issue_half(0, 1, 1); issue_half(1, 1, 1); }
+                if (PH == 2)      { issue_half(2, 1, 1); issue_half(3, 1, 1); }                   // two-phase loop: W of K-tile 1
+                else if (PH == 1) { issue_half(0, 1, 1); issue_half(1, 1, 1); }                   // pipelined loop: A of K-tile 1
+                else              { issue_half(2, 1, 1); issue_half(0, 1, 1); issue_half(1, 1, 1); }
             }
         } else {
             issue_h(2, 0, 0); issue_h(0, 0, 0); issue_h(3, 0, 0);
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // The hazard analysis above is unchanged: it is the same schedule with tile indices taken modulo the unit.  Units next to a half
     // unit (other stage geometry) and single-K-tile units start from the burst as before, with sb = 0.
     int ui = 0, sb = 0;
+    bool streamed_in = false;                               // this unit's first K-tiles were issued inside the previous unit's K loop
     bool have = get_unit(0);
     int cur_tile = u_tile, cur_mode = u_mode;
     if (have) { set_tile(cur_tile, cur_mode); issue_prologue(KT, cur_mode); }
@@ -600,18 +605,134 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         // K-tile 0 has landed when at most the 6 DMAs of K-tile 1 issued by the prologue (W0 / A0 / A1 of a whole tile, all of a half
         // unit's) are still in flight.  (After the first unit the previous epilogue's stores are younger than these DMAs and count too: the
         // wait is then stronger, never weaker.)
+        // (pipelined loop, unit streamed into: the previous unit's last barrier has already published this unit's K-tile 0)
+        if (!(PH == 1 && streamed_in)) {
         if (nkt > 1) {
-            if (PH2 && !halfu) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (PH != 4 && !halfu) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else               asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();            // the late group starts one interval later
+        if (wm == 1 && (PH != 1 || halfu)) __builtin_amdgcn_s_barrier();   // the late group starts one interval later (phase loops)
+        }
         PH_STAMP(sbase + 1);                                // K-tile 0 landed, K loop starts
 
         v8 af[4][2], bf0[2][2], bf1[2][2];                // A: 4 m-tiles x 2 k-steps; W: 2 n-tiles x 2 k-steps, for j = 0 and j = 1
-        if (!halfu && PH2) {
+        if (!halfu && PH == 1) {
+        // SOFTWARE-PIPELINED loop, ONE barrier per K-tile (switch bf16_gemm_phases = 1).  The phase loops separate a wave's LDS reads /
+        // DMA issue (L-segment) from its MFMAs (C-segment) with a barrier and run the two waves of a SIMD in opposite roles; the
+        // stamps and ablations of round 3 say what that costs: a K-tile's 64 MFMAs per wave are 1.0 us of matrix pipe for the SIMD's
+        // two waves, the barrier skeleton alone (8 intervals) 0.69 us, the loop 1.5-1.6 us -- an interval is as long as the LONGER of
+        // one wave's L-segment and the other's C-segment plus a barrier turn-around.  Here every wave runs ONE stream per K-tile: four
+        // quarters of 16 MFMAs (quarter (ks, i): k-step ks of the K-tile, 64-row half i of the wave's rows, all 4 n-tiles), and among
+        // the MFMAs of a quarter it reads the NEXT quarter's fragments into the other half of a double buffer (fa0 / fa1, fw0 / fw1:
+        // the same 64 fragment registers as the phase loops) and issues its LDS-DMA pieces; hipcc counts lgkmcnt for the fragment
+        // reads itself (it sees them), the DMAs stay hidden and hand-counted.  Nothing separates the two waves of a SIMD: the hardware
+        // issues one wave's MFMAs under the other's reads and DMA issue.
+        //   q0 (ks0, i0): reads A(ks0, i1);              issues W0, W1 of K-tile u+1 (4 pieces per wave)
+        //   q1 (ks0, i1): reads A(ks1, i0) and W(ks1)
+        //   q2 (ks1, i0): reads A(ks1, i1);              then lgkmcnt(0), vmcnt(0), BARRIER
+        //   q3 (ks1, i1): reads A(ks0, i0), W(ks0) of K-tile u+1 (other stage);   issues A0, A1 of K-tile u+2 (4 pieces)
+        //   WAR : the stage of K-tile u is last read in q2 (complete before the barrier: lgkmcnt(0)); its refill (A of K-tile u+2 in
+        //         q3 of K-tile u, W of K-tile u+2 in q0 of K-tile u+1) is issued after that barrier.
+        //   RAW : K-tile u+1 (A issued in q3 of K-tile u-1, W in q0 of K-tile u; nothing younger) is first read in q3 of K-tile u; every
+        //         wave waits for ITS pieces with vmcnt(0) at the end of q2 and the barrier publishes them.  A has a whole K-tile of
+        //         lookahead, the L2-resident W three quarters.
+        // Unit start: K-tile 0 landed and published, A of K-tile 1 in flight (prologue: K-tile 0 + A of K-tile 1; streamed into: the
+        // same state, left by the previous unit's last two K-tiles); the unit's first fragments are read outside the pipeline.
+        v8 fa0[4], fa1[4], fw0[4], fw1[4];
+        auto rdA = [&](const float4* sa_, int i, int ks, int m) -> v8 {
+            const float4 v = sa_[((i * 4 + m) * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+            return *reinterpret_cast<const v8*>(&v);
+        };
+        auto rdW = [&](const float4* sw_, int ks, int n) -> v8 {
+            const float4 v = sw_[(n * 16 + c) * 8 + ((ks * 4 + g) ^ (c & 7))];
+            return *reinterpret_cast<const v8*>(&v);
+        };
+        auto issue_piece = [&](int hid, int i, int kt, int stage) {   // one 1 KiB piece of half-tile hid (issue_half = pieces 0 and 1)
+            const int row0 = (hid & 1) * 128 + (wave * 2 + i) * 8;
+            const unsigned dst = lds_base + (unsigned)(stage * STAGE + (hid >= 2 ? SA : 0) + row0 * 8) * 16u;
+            glds16_hidden_s((hid >= 2 ? wbase : abase) + kt * 128, voff[hid][i], dst);
+        };
+        {
+            const float4* sbuf = lds + (sb & 1) * STAGE;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                fa0[m] = rdA(sbuf + (wm * 128) * 8, 0, 0, m);
+                fw0[m] = rdW(sbuf + SA + (wn * 64) * 8, 0, m);
+            }
+        }
+        if (PH_ABLATE(1)) {                                   // (tools-only ablation without fragment reads: defined, opaque operands)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { fa1[m] = fa0[m]; fw1[m] = fw0[m]; asm volatile("" : "+v"(fa1[m]), "+v"(fw1[m])); }
+        }
+        for (int u = 0; u < nkt; ++u) {
+            const float4* sbuf = lds + ((u + sb) & 1) * STAGE;
+            const float4* sa = sbuf + (wm * 128) * 8;
+            const float4* sw = sbuf + SA + (wn * 64) * 8;
+            const float4* nbuf = lds + ((u + 1 + sb) & 1) * STAGE;
+            const float4* nsa = nbuf + (wm * 128) * 8;
+            const float4* nsw = nbuf + SA + (wn * 64) * 8;
+            const int g1 = u + 1, g2 = u + 2;               // K-tiles the DMAs of this K-tile belong to (>= nkt: the next unit's)
+            const bool i1 = g1 < nkt || stream, i2 = g2 < nkt || stream;
+            const int k1 = g1 < nkt ? g1 : g1 - nkt, k2 = g2 < nkt ? g2 : g2 - nkt;
+            const bool nxt = g1 < nkt;
+            // (reads come BEFORE the MFMAs of their group and in the first groups of a quarter, W fragments first: the next quarter's
+            // first group needs all four W fragments and A fragment 0, and nothing is waited for right after it was requested)
+            // ---------------- q0
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (!PH_ABLATE(1)) fa1[m] = rdA(sa, 1, 0, m);
+                if (i1 && !PH_ABLATE(0)) issue_piece(2 + (m >> 1), m & 1, k1, (g1 + sb) & 1);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) if (!PH_ABLATE(2)) acc[n][m] = X16<T>::mfma(fw0[n], fa0[m], acc[n][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---------------- q1
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (!PH_ABLATE(1)) {
+                if (m == 0) { fw1[0] = rdW(sw, 1, 0); fw1[1] = rdW(sw, 1, 1); fw1[2] = rdW(sw, 1, 2); }
+                if (m == 1) { fw1[3] = rdW(sw, 1, 3); fa0[0] = rdA(sa, 0, 1, 0); fa0[1] = rdA(sa, 0, 1, 1); }
+                if (m == 2) { fa0[2] = rdA(sa, 0, 1, 2); fa0[3] = rdA(sa, 0, 1, 3); }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) if (!PH_ABLATE(2)) acc[n][4 + m] = X16<T>::mfma(fw0[n], fa1[m], acc[n][4 + m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (stream && u == nkt - 2) {                     // this unit's last DMA is out (q0): the next unit's addresses
+                int t = nx_tile;
+                asm volatile("" : "+s"(t));                   // (opaque: hipcc otherwise computes the next unit's 8 offsets at the unit start and keeps them live)
+                set_tile(t, 0);
+            }
+            // ---------------- q2
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < 2 && !PH_ABLATE(1)) { fa1[2 * m] = rdA(sa, 1, 1, 2 * m); fa1[2 * m + 1] = rdA(sa, 1, 1, 2 * m + 1); }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) if (!PH_ABLATE(2)) acc[n][m] = X16<T>::mfma(fw1[n], fa0[m], acc[n][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of this stage is in registers before anyone may refill it
+            if (i1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of K-tile u+1 have landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- q3
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (nxt && !PH_ABLATE(1)) {
+                    if (m == 0) { fw0[0] = rdW(nsw, 0, 0); fw0[1] = rdW(nsw, 0, 1); fw0[2] = rdW(nsw, 0, 2); }
+                    if (m == 1) { fw0[3] = rdW(nsw, 0, 3); fa0[0] = rdA(nsa, 0, 0, 0); fa0[1] = rdA(nsa, 0, 0, 1); }
+                    if (m == 2) { fa0[2] = rdA(nsa, 0, 0, 2); fa0[3] = rdA(nsa, 0, 0, 3); }
+                }
+                if (i2 && !PH_ABLATE(0)) issue_piece(m >> 1, m & 1, k2, (g2 + sb) & 1);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) if (!PH_ABLATE(2)) acc[n][4 + m] = X16<T>::mfma(fw1[n], fa1[m], acc[n][4 + m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        } else if (!halfu && PH == 2) {
         // TWO phases of 32 MFMAs per K-tile (switch bf16_gemm_phases = 2).  Compile-time ablations of the four-phase loop
         // (tools/gemm_bf16_ablate.sh) put the skeleton of a K-tile -- 8 barrier-to-barrier intervals with their reads and DMAs but
         // no MFMA -- at 0.89 us and its 64 MFMAs per wave at 1.0 us of matrix pipe for the SIMD's two waves, yet the loop takes 1.6 us:
@@ -809,7 +930,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
             st3n = st3n == 2 ? 0 : st3n + 1;
         }
         }
-        if (wm == 0) __builtin_amdgcn_s_barrier();            // the early group waits out the late group's last C-segment
+        if (wm == 0 && (PH != 1 || halfu)) __builtin_amdgcn_s_barrier();   // the early group waits out the late group's last C-segment
         PH_STAMP(sbase + 2);                                // K loop done
 
         // Both operand stages are free now (every read of the last K-tiles completed before the barriers above).  Epilogues without a
@@ -835,6 +956,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         if (have && !stream) set_tile(nx_tile, nx_mode);   // (stream: done inside the K loop, and the next unit's K-tile 0 has landed)
         if (!RESV && have && !stream) issue_prologue(KT, nx_mode);
         sb = stream ? (sb + nkt) & 1 : 0;
+        streamed_in = stream;
 
         const int kpass = halfu ? 2 : 4;                       // epilogue passes of 2 m-tiles per wave row (a half unit has 4 m-tiles)
         PH_STAMP(sbase + 3);                                // next unit's prologue issued (RESV: only its addresses are ready)
@@ -1026,14 +1148,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     }
 }
 
-template <int EPI, typename T, bool PH2>
+template <int EPI, typename T, int PH>
 static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
                       int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp) {
     const int shmem = 2 * (256 + 256) * 128 + 32768;   // two operand stages + the C stage: all 160 KB of the CU's LDS
     DeviceInfo di;
     MGEA_TRY(device_info(&di));
     static uint64_t attr_done = 0;                      // per instantiation, one bit per device
-    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI, T, PH2>), shmem, di.dev, &attr_done));
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16_ph_kernel<EPI, T, PH>), shmem, di.dev, &attr_done));
     const int tm = ceil_div(M, 256), tn = ceil_div(N, 256), n_tiles = tm * tn;
     const int n_cu = di.n_cu / 8 * 8;
     const int grid = (int)round_up(n_tiles < n_cu ? n_tiles : n_cu, 8);   // one persistent workgroup per CU (160 KB of LDS each)
@@ -1044,7 +1166,7 @@ static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bia
         info->kernel = 2;
         info->half_tiles = ((tail & 3) != 0 && rem > 0 && 2 * rem <= wg_x) ? 1 : 0;
     }
-    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T, PH2>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
+    hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, T, PH>), dim3(grid), dim3(512), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles,
                        tail, lnp ? *lnp : BfEpiLn{nullptr, nullptr, nullptr, nullptr, nullptr});
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
@@ -1052,8 +1174,10 @@ static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bia
 template <int EPI, typename T = bf16_t>
 static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
                      int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
-    if (tune(TUNE_BF16_GEMM_PHASES) == 2) return launch_ph2<EPI, T, true>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
-    return launch_ph2<EPI, T, false>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    const int ph = tune(TUNE_BF16_GEMM_PHASES);
+    if (ph == 1) return launch_ph2<EPI, T, 1>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    if (ph == 2) return launch_ph2<EPI, T, 2>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
+    return launch_ph2<EPI, T, 4>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info, lnp);
 }
 
 template <int EPI, int NT, int WMW>

@@ -27,7 +27,7 @@ const TuneEntry kTune[] = {
     {TUNE_BF16_GEMM_TILE, "bf16_gemm_tile", "MGEA_BF16_GEMM_TILE", 0},
     {TUNE_BF16_GEMM_SMALL, "bf16_gemm_small", "MGEA_BF16_GEMM_SMALL", 0},
     {TUNE_BF16_GEMM_TAIL, "bf16_gemm_tail", "MGEA_BF16_GEMM_TAIL", 2},
-    {TUNE_BF16_GEMM_PHASES, "bf16_gemm_phases", "MGEA_BF16_GEMM_PHASES", 4},
+    {TUNE_BF16_GEMM_PHASES, "bf16_gemm_phases", "MGEA_BF16_GEMM_PHASES", 2},
     {TUNE_BF16_GEMM_REVERSE, "bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
     {TUNE_BERT_BF16_NOFOLD, "bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
     {TUNE_DECODER_UNFUSED, "decoder_unfused", "MGEA_DECODER_UNFUSED", 0},

@@ -43,7 +43,7 @@ const char* get_error();
 enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 256x128 / 3 256x256 ring kernels; 4 = the persistent 256x256 kernel
        TUNE_BF16_GEMM_SMALL,      // 1: the register-staged 128x128 kernel for every shape
        TUNE_BF16_GEMM_TAIL,       // persistent kernel, tiles left after the full rounds: 0 whole tiles, 1 two 128-row halves, 2 = 1 + staggered order
-       TUNE_BF16_GEMM_PHASES,     // whole tiles of the persistent kernel: 4 phases of 16 MFMAs per K-tile, or 2 phases of 32
+       TUNE_BF16_GEMM_PHASES,     // whole tiles of the persistent kernel: 4 phases of 16 MFMAs per K-tile, 2 (default) phases of 32, or 1 = software-pipelined, one barrier per K-tile
        TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()

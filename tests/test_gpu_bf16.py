@@ -115,7 +115,7 @@ BF16_REL = 4.3e-3
 
 @pytest.mark.parametrize("N,K,epi", [(768, 768, 5), (768, 3072, 5), (2304, 768, 3), (3072, 768, 4), (2304, 768, 0), (768, 3072, 2),
                                      (3072, 768, 1), (768, 768, 2)])
-@pytest.mark.parametrize("phases", [4, 2])
+@pytest.mark.parametrize("phases", [4, 2, 1])
 def test_gemm_bf16_bench_shape_every_epilogue_and_tail_schedule(N, K, epi, phases, tune):
     """The kernel combination the bf16 DistilBERT engine runs at BASELINE configs[1] (B = 256, S = 128 -> M = 32768): the
     persistent 256 x 256 kernel with epilogues 3 (QKV, folded LayerNorm), 4 (FC1, + GELU) and 5 (out-proj and FC2: LayerNorm of
@@ -126,7 +126,7 @@ def test_gemm_bf16_bench_shape_every_epilogue_and_tail_schedule(N, K, epi, phase
     output it wrote; and whole tiles (tail 0) / half tiles (1) / staggered half tiles (2) BITWISE equal -- every output element
     sees the same MFMA sequence over K whichever workgroup computes it."""
     from mgea import ops
-    tune("bf16_gemm_phases", phases)            # whole tiles in 4 phases of 16 MFMAs per K-tile, or in 2 phases of 32 (another schedule, same sums)
+    tune("bf16_gemm_phases", phases)            # whole tiles in 4 phases of 16 MFMAs per K-tile, in 2 phases of 32, or software-pipelined with one barrier per K-tile (other schedules, same sums)
     M = 32768
     a, w, b, (want, scale), kw = _gemm_case(M, N, K, epi)
     outs = {}
@@ -160,7 +160,7 @@ def test_gemm_bf16_bench_shape_every_epilogue_and_tail_schedule(N, K, epi, phase
 
 @pytest.mark.parametrize("M,N,K", [(8192, 4096, 192), (12288, 2048, 320), (8448, 2304, 448), (16384, 768, 64), (5000, 4096, 192)])
 @pytest.mark.parametrize("epi", [0, 2, 5])
-@pytest.mark.parametrize("phases", [4, 2])
+@pytest.mark.parametrize("phases", [4, 2, 1])
 def test_gemm_bf16_stream_across_tiles_with_odd_k_tiles(M, N, K, epi, phases, tune):
     """Several whole tiles per workgroup with an ODD number of K-tiles (3, 5, 7) and with a single one: between two whole tiles the
     LDS-DMA stream continues over the boundary and the stage a K-tile lands in alternates with the running parity (sb), which the

@@ -18,6 +18,12 @@ lib.mgea_dbg_set_ph_stamps.restype = C.c_int
 lib.mgea_dbg_set_ph_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(256, 64, dtype=torch.int64, device="cuda")
 assert lib.mgea_dbg_set_ph_stamps(C.c_void_p(stamps.data_ptr())) == 0
+lib.mgea_dbg_set_ph_cycles.restype = C.c_int
+lib.mgea_dbg_set_ph_cycles.argtypes = [C.c_void_p]
+cycles = torch.zeros(256, 64, dtype=torch.int64, device="cuda")     # s_memtime at the same points: the clock a span was run at
+assert lib.mgea_dbg_set_ph_cycles(C.c_void_p(cycles.data_ptr())) == 0
+PH = int(os.environ.get("MGEA_BF16_GEMM_PHASES", "0") or 0)
+if PH: print(f"bf16_gemm_phases = {PH}")
 lib.mgea_dbg_set_ph_same_tile.restype = C.c_int
 lib.mgea_dbg_set_ph_same_tile.argtypes = [C.c_int]
 SAME = len(sys.argv) > 1 and sys.argv[1] == "same_tile"      # ablation: every unit loads tile 0's operands (L2-resident; wrong results)
@@ -39,15 +45,21 @@ for name, N, K, epi in [("qkv", 2304, 768, 3), ("out", 768, 768, 5), ("fc1", 307
     elif epi == 5:
         kw = dict(res=r, ln=dict(rowstat=st, g=torch.ones(N, device="cuda"), b=torch.zeros(N, device="cuda"), stats=torch.zeros(M, N // 256, 2, device="cuda")))
     kw["out"] = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    for _ in range(5): ops.gemm_bf16(a, w, b, **kw)
+    for _ in range(int(os.environ.get('STAMPS_WARM', '3000'))): ops.gemm_bf16(a, w, b, **kw)      # the clock settles under sustained load only
     torch.cuda.synchronize()
-    stamps.zero_()
+    stamps.zero_(); cycles.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.gemm_bf16(a, w, b, **kw); e1.record(); torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.float64) / 100.0      # us
     t0 = s[:, 0].min()
     print(f"== {name} N={N} K={K} epi {epi}: launch {e0.elapsed_time(e1) * 1e3:.1f} us; kernel span by stamps {s.max() - t0:.1f} us; "
           f"workgroup start skew {np.percentile(s[:, 0] - t0, 50):.2f} / {np.percentile(s[:, 0] - t0, 99):.2f} us (median / p99)")
+    cy = cycles.cpu().numpy().astype(np.float64)
+    ok = (s[:, 2] > s[:, 1]) & (cy[:, 2] > cy[:, 1])
+    if ok.any():   # shader clock over the first unit's K loop and over the whole kernel, median over workgroups
+        last = np.array([np.flatnonzero(s[i] > 0).max() for i in range(s.shape[0])])
+        whole = np.array([(cy[i, last[i]] - cy[i, 0]) / max(s[i, last[i]] - s[i, 0], 1e-9) for i in range(s.shape[0])])
+        print(f"  in-kernel clock: K loop of unit 0 {np.median((cy[ok, 2] - cy[ok, 1]) / (s[ok, 2] - s[ok, 1])) / 1e3:.3f} GHz, whole kernel {np.median(whole) / 1e3:.3f} GHz")
     for u in range(3):
         base = u * 12
         if not (s[:, base] > 0).any():

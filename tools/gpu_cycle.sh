@@ -21,6 +21,7 @@ for s in $STEPS; do
     bf16tests) run bf16tests 900 python3 -m pytest tests/test_gpu_bf16.py -x -q -m gpu -s || exit 1 ;;
     alltests)  run alltests 1100 python3 -m pytest tests -x -q -m gpu || exit 1 ;;
     gemmbench) run gemmbench 300 python3 tools/gemm_bf16_bench.py || exit 1 ;;
+    phasesab)  run phasesab 300 python3 tools/gemm_bf16_phases_ab.py || exit 1 ;;
     stress)    run stress 400 python3 tools/gemm_bf16_stress.py 200 noise || exit 1 ;;
     bench)     run bench 400 python3 bench.py --steps 2 --warmup 1 --no-cpu || exit 1 ;;
     benchfull) run benchfull 600 python3 bench.py || exit 1 ;;
@@ -40,7 +41,7 @@ for s in $STEPS; do
     prefillab) run prefillab 300 python3 tools/prefill_ab.py decoder_prefill16_overlap 0 1 || exit 1 ;;
     attnwide)  run attnwide 300 python3 tools/prefill_ab.py attn16_wide 0 1 || exit 1 ;;
     attnstamps) run attnstamps 300 python3 tools/attn_stamps.py || exit 1 ;;
-    bertph)    run bertph 300 python3 tools/bert_ab.py bf16_gemm_phases 4 2 || exit 1 ;;
+    bertph)    run bertph 300 python3 tools/bert_ab.py bf16_gemm_phases 4 2 1 || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
