@@ -1171,6 +1171,189 @@ static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bia
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
+// ------------------------------------------------------------------------------------------
+// TWO WORKGROUPS PER CU ("duo"): 256 x 128 of C per workgroup of 4 waves (2 x 2, the same 128 x 64 per wave and the same fragment
+// registers as the 256 x 256 kernel), 72 KB of LDS each, so that a CU holds two of them and they run INDEPENDENTLY: while one is in
+// its epilogue (VALU, LDS, global stores; matrix pipe idle), waiting at a barrier or issuing LDS-DMA, the other one's waves have the
+// matrix pipe of every SIMD to themselves.  The 8-wave kernel above is one workgroup whose waves all reach the epilogue together:
+// stamps put 24-42 % of a tile's time outside the K loop at K = 768 (VERDICT r2 #2 asks for exactly this overlap).  Price: the tile
+// has 1.5 x the operand bytes per FLOP, (256 + 128) x 32 x 2 B = 24 KB per K-step of 32.
+//   LDS  : three stages of 24 KB (A 256 rows x 64 B, then W 128 rows x 64 B), rows of FOUR 16-byte chunks, chunk slot = chunk ^ f(row / 4 % 4),
+//          f = (0, 2, 3, 1): the four 16-lane groups a ds_read_b128 is served in ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md) each touch
+//          the 16 bank groups once.  LDS-DMA pieces of 16 rows (lane -> row lane / 4, slot lane % 4; swizzle on the source side).
+//   loop : per K-step j (32 MFMAs per wave on fragments already in registers): lgkmcnt(0) (stage j % 3 is consumed), wait for this
+//          wave's pieces of step j+1 (vmcnt(6): step j+2's six may fly), ONE barrier; then among the MFMAs the 12 fragment reads of step
+//          j+1 (other half of a double buffer) and the six pieces of step j+3 into stage j % 3.
+//   tile : the whole 256 x 128 bf16 tile (64 KB) is staged through the ring after the K loop, one barrier, whole-row stores.
+template <int EPI, typename T>
+__global__ __launch_bounds__(256, 2) void gemm16_duo_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                        const float* __restrict__ bias, const T* __restrict__ res,
+                                                        T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles) {
+    typedef typename X16<T>::v8 v8;
+    typedef typename X16<T>::v4 v4;
+    constexpr int BM = 256, BN = 128;
+    constexpr int SA = BM * 4, STAGE = (BM + BN) * 4;     // in 16-byte chunks
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [3][STAGE] = 72 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KS = K >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
+    auto fsw = [](int q) { return (0x78 >> (2 * q)) & 3; };
+    // the XCD's contiguous run of tiles, walked with stride gridDim.x / 8 (speed only)
+    const int wg_x = gridDim.x >> 3, slot = (int)blockIdx.x >> 3;
+    const int run_len = (n_tiles + 7) >> 3, run0 = ((int)blockIdx.x & 7) * run_len;
+    const int per_x = run0 + run_len < n_tiles ? run_len : n_tiles - run0;
+    // fragment read offsets (16-byte chunks inside a stage): row c of m-tile / n-tile 0, k-chunk g
+    const int frag = c * 4 + (g ^ fsw(c >> 2));
+    // DMA: lane -> row lane / 4 of its piece, source chunk (lane % 4) ^ f(lane / 16)   [(row / 4) % 4 == lane / 16 inside a 16-row piece]
+    const int prow = lane >> 2, pch = (lane & 3) ^ fsw(lane >> 4);
+    for (int it = slot; it < per_x; it += wg_x) {
+        const int t = run0 + it;
+        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+        unsigned voa[4], vow[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = (wave * 4 + i) * 16 + prow;
+            r = m0 + r < M ? r : M - 1 - m0;
+            voa[i] = (unsigned)(r * lda + pch * 8) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = (wave * 2 + i) * 16 + prow;
+            r = n0 + r < N ? r : N - 1 - n0;
+            vow[i] = (unsigned)(r * ldw + pch * 8) * 2u;
+        }
+        const char* abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
+        const char* wbase = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw);
+        auto issue_step = [&](int j, int st) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds16_hidden_s(abase + j * 64, voa[i], lds_base + (unsigned)(st * STAGE + (wave * 4 + i) * 64) * 16u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                glds16_hidden_s(wbase + j * 64, vow[i], lds_base + (unsigned)(st * STAGE + SA + (wave * 2 + i) * 64) * 16u);
+        };
+        // prologue: steps 0, 1, 2 in flight; step 0 landed and published; its fragments read outside the pipeline
+        issue_step(0, 0);
+        if (KS > 1) issue_step(1, 1);
+        if (KS > 2) issue_step(2, 2);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (KS > 2)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (KS > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // Fragments: W double-buffered (fw0 / fw1); A refilled IN PLACE -- the MFMAs run m-tile by m-tile, fa[m] is dead after its four
+        // MFMAs and is re-read for step j+1 right behind them -- except m-tiles 6 and 7, whose refill would be requested at the very end
+        // of the step and waited for at the top of the next: those two alternate between fa[6], fa[7] and the spare pair fs[0], fs[1],
+        // requested at the START of the step.  72 fragment registers instead of the 96 of a full double buffer (which spilled 23).
+        v8 fa[8], fs[2], fw0[4], fw1[4];
+        auto rd = [&](const float4* p_) -> v8 { const float4 v = *p_; return *reinterpret_cast<const v8*>(&v); };
+        {
+            const float4* sa = lds + (wm * 128) * 4 + frag;
+            const float4* sw = lds + SA + (wn * 64) * 4 + frag;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fw0[n] = rd(sw + n * 64);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) fa[m] = rd(sa + m * 64);
+        }
+        // one step: 32 MFMAs on (fwc, fa[0..5], c6, c7); among them the 12 fragment reads of step j+1 (stage s1) into (fwn, fa[0..5], n6, n7)
+        // and this wave's six pieces of step j+3 into the stage step j has just vacated (s0)
+        auto step = [&](int j, int s0, int s1, v8 (&fwc)[4], v8 (&fwn)[4], v8& c6, v8& c7, v8& n6, v8& n7) {
+            // top: every read of step j's fragments is complete (stage s0 is consumed), this wave's pieces of step j+1 have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (j + 2 < KS)      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (j + 1 < KS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            const bool nx = j + 1 < KS, dma = j + 3 < KS;
+            const float4* sa = lds + s1 * STAGE + (wm * 128) * 4 + frag;
+            const float4* sw = lds + s1 * STAGE + SA + (wn * 64) * 4 + frag;
+            if (nx) {
+                fwn[0] = rd(sw); fwn[1] = rd(sw + 64); fwn[2] = rd(sw + 128); fwn[3] = rd(sw + 192);
+                n6 = rd(sa + 6 * 64); n7 = rd(sa + 7 * 64);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (dma && m < 6) {                           // pieces 0..3: A, 4..5: W
+                    if (m < 4) glds16_hidden_s(abase + (j + 3) * 64, voa[m], lds_base + (unsigned)(s0 * STAGE + (wave * 4 + m) * 64) * 16u);
+                    else       glds16_hidden_s(wbase + (j + 3) * 64, vow[m - 4], lds_base + (unsigned)(s0 * STAGE + SA + (wave * 2 + m - 4) * 64) * 16u);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const v8 av = m == 6 ? c6 : (m == 7 ? c7 : fa[m]);
+                    acc[n][m] = X16<T>::mfma(fwc[n], av, acc[n][m]);
+                }
+                if (nx && m < 6) fa[m] = rd(sa + m * 64);      // in place, behind its last use
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            int s0 = 0, s1 = 1;
+            for (int j = 0; j < KS; j += 2) {                 // (K % 64 == 0: an even number of steps)
+                step(j, s0, s1, fw0, fw1, fa[6], fa[7], fs[0], fs[1]);
+                s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
+                step(j + 1, s0, s1, fw1, fw0, fs[0], fs[1], fa[6], fa[7]);
+                s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
+            }
+        }
+        // epilogue: the tile as bf16 through the ring (row pitch 256 B, 16-byte chunk XOR-swizzled by the row), whole-row stores
+        __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
+        unsigned char* sC = reinterpret_cast<unsigned char*>(lds);
+        int tid_o = tid, c_o = c, g_o = g;                    // opaque per-tile copies: hipcc otherwise computes every epilogue address
+        asm volatile("" : "+v"(tid_o), "+v"(c_o), "+v"(g_o));  // (thread-index-only arithmetic) before the K loop and keeps it live through it
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int lcol = wn * 64 + n * 16 + 4 * g_o;
+            const int col = n0 + lcol;
+            const float4 bv = (bias && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int row = wm * 128 + m * 16 + c_o;
+                float4 v = add4(make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]), bv);
+                if (EPI == BEPI_BIAS_GELU) {
+                    const f32x2 g0 = gelu_fast2((f32x2){v.x, v.y}), g1 = gelu_fast2((f32x2){v.z, v.w});
+                    v = make_float4(g0[0], g0[1], g1[0], g1[1]);
+                }
+                v4 o = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                *reinterpret_cast<v4*>(sC + row * 256 + (((lcol >> 3) ^ (row & 15)) * 16) + (lcol & 7) * 2) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                        // 256 rows x 16 chunks / 256 threads
+            const int id = tid_o + i * 256, row = id >> 4, ch = id & 15;
+            const u32x4 vw = *reinterpret_cast<const u32x4*>(sC + row * 256 + ((ch ^ (row & 15)) * 16));
+            const int grow = m0 + row, gcol = n0 + ch * 8;
+            if (grow < M && gcol < N) *reinterpret_cast<u32x4*>(C + (int64_t)grow * ldc + gcol) = vw;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // the ring is free for the next tile's first pieces
+    }
+}
+
+template <int EPI, typename T>
+static int launch_duo(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
+                      int N, int K, hipStream_t st) {
+    const int shmem = 3 * (256 + 128) * 64;             // 72 KB: two workgroups per CU
+    DeviceInfo di;
+    MGEA_TRY(device_info(&di));
+    static uint64_t attr_done = 0;
+    MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm16_duo_kernel<EPI, T>), shmem, di.dev, &attr_done));
+    const int tm = ceil_div(M, 256), tn = ceil_div(N, 128), n_tiles = tm * tn;
+    const int slots = 2 * (di.n_cu / 8 * 8);
+    const int grid = (int)round_up(n_tiles < slots ? n_tiles : slots, 8);
+    hipLaunchKernelGGL((gemm16_duo_kernel<EPI, T>), dim3(grid), dim3(256), shmem, st, a, lda, w, ldw, bias, r, c, ldc, M, N, K, tn, n_tiles);
+    MGEA_CHECK_HIP(hipGetLastError());
+    return MGEA_OK;
+}
+
 template <int EPI, typename T = bf16_t>
 static int launch_ph(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
                      int N, int K, hipStream_t st, GemmBf16Info* info, const BfEpiLn* lnp = nullptr) {
@@ -1211,6 +1394,10 @@ template <int EPI>
 static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
                             int ldc, int M, int N, int K, hipStream_t st, GemmBf16Info* info) {
     const int force = tune(TUNE_BF16_GEMM_TILE);   // 1: 128x128 / 2: 256x128 / 3: 256x256 ring kernels (tools/gemm_bf16_bench.py)
+    if (force == 5 && EPI != BEPI_BIAS_RES && K % 32 == 0 && N % 8 == 0) {   // (prototype switch: the two-workgroups-per-CU kernel)
+        if (info) { info->kernel = 3; info->half_tiles = 0; }
+        return launch_duo<EPI, bf16_t>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
+    }
     if (pick_bf16_kernel(M, N, K, ldc) == 2) return launch_ph<EPI>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st, info);
     if (info) { info->kernel = 1; info->half_tiles = 0; }
     if (force == 1) return launch_glds<EPI, 2, 1>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
