@@ -1173,136 +1173,113 @@ static int launch_ph2(const T* a, int lda, const T* w, int ldw, const float* bia
 }
 // ------------------------------------------------------------------------------------------
 // TWO WORKGROUPS PER CU ("duo"): 256 x 128 of C per workgroup of 4 waves (2 x 2, the same 128 x 64 per wave and the same fragment
-// registers as the 256 x 256 kernel), 72 KB of LDS each, so that a CU holds two of them and they run INDEPENDENTLY: while one is in
-// its epilogue (VALU, LDS, global stores; matrix pipe idle), waiting at a barrier or issuing LDS-DMA, the other one's waves have the
+// layout as the 256 x 256 kernel), 80 KB of LDS each, so that a CU holds two of them and they run INDEPENDENTLY: while one is in
+// its epilogue (VALU, LDS, global stores; matrix pipe idle), waiting at a barrier or for its fragments, the other one's waves have the
 // matrix pipe of every SIMD to themselves.  The 8-wave kernel above is one workgroup whose waves all reach the epilogue together:
 // stamps put 24-42 % of a tile's time outside the K loop at K = 768 (VERDICT r2 #2 asks for exactly this overlap).  Price: the tile
-// has 1.5 x the operand bytes per FLOP, (256 + 128) x 32 x 2 B = 24 KB per K-step of 32.
-//   LDS  : three stages of 24 KB (A 256 rows x 64 B, then W 128 rows x 64 B), rows of FOUR 16-byte chunks, chunk slot = chunk ^ f(row / 4 % 4),
-//          f = (0, 2, 3, 1): the four 16-lane groups a ds_read_b128 is served in ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md) each touch
-//          the 16 bank groups once.  LDS-DMA pieces of 16 rows (lane -> row lane / 4, slot lane % 4; swizzle on the source side).
-//   loop : per K-step j (32 MFMAs per wave on fragments already in registers): lgkmcnt(0) (stage j % 3 is consumed), wait for this
-//          wave's pieces of step j+1 (vmcnt(6): step j+2's six may fly), ONE barrier; then among the MFMAs the 12 fragment reads of step
-//          j+1 (other half of a double buffer) and the six pieces of step j+3 into stage j % 3.
-//   tile : the whole 256 x 128 bf16 tile (64 KB) is staged through the ring after the K loop, one barrier, whole-row stores.
+// has 1.5 x the operand bytes per FLOP.
+//   LDS  : K-tiles of 64 (whole 128-byte lines per row: a first version with K-steps of 32 and a three-stage ring made 64-byte requests,
+//          3 x the L2 requests of the 256 x 256 kernel per FLOP, and ran at 0.77 of its rate -- profiles/r3_gemm_duo_bk32_*).  80 KB hold
+//          TWO A stages (256 rows x 128 B = 32 KB each) and ONE W buffer (128 rows, 16 KB): W is the operand that sits in L2, its K-tile
+//          is read into registers (8 fragments, both k-steps) at the top of a K-tile and refilled behind a second barrier.
+//   loop : K-tile u: vmcnt(0) [A(u), W(u): nothing younger], barrier B1 (publishes them; A stage (u+1) & 1 is free: every wave has left
+//          K-tile u-1); read the 8 W fragments and the 8 A fragments of k-step 0; lgkmcnt(0), barrier B2 (the W buffer is free);
+//          then 64 MFMAs, m-tile by m-tile, with the A fragments of k-step 1 refilled in place behind their last use, and among them
+//          this wave's 8 pieces of A(u+1) and 4 of W(u+1).  The exposed reads at the top are what the OTHER workgroup covers.
+//   tile : the whole 256 x 128 bf16 tile (64 KB) is staged through the two A stages after the K loop, one barrier, whole-row stores.
+// MEASURED (round 3, in-process A/B against the 256 x 256 kernel, outputs bitwise equal; profiles/r3_gemm_duo_*): 0.92 of its rate on QKV
+// (K = 768), 0.91 on FC1 with GELU -- the GELU costs this kernel what it costs the other one, nothing hides it --, 0.99 on the out-proj shape,
+// 0.93 at K = 3072; 1.25 x at K = 192 and 1.05 x at 8192^3.  Delaying one workgroup of every CU by 4-16 us changes nothing.  NOT the engine's
+// choice: switch bf16_gemm_tile = 5, plain epilogues (bias, bias + GELU) only.
 template <int EPI, typename T>
 __global__ __launch_bounds__(256, 2) void gemm16_duo_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
-                                                        const float* __restrict__ bias, const T* __restrict__ res,
-                                                        T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles) {
+                                                           const float* __restrict__ bias, const T* __restrict__ res,
+                                                           T* __restrict__ C, int ldc, int M, int N, int K, int tiles_n, int n_tiles) {
     typedef typename X16<T>::v8 v8;
     typedef typename X16<T>::v4 v4;
     constexpr int BM = 256, BN = 128;
-    constexpr int SA = BM * 4, STAGE = (BM + BN) * 4;     // in 16-byte chunks
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [3][STAGE] = 72 KB
+    constexpr int SA = BM * 8, WOFF = 2 * SA;               // in 16-byte chunks: two A stages, then the W buffer
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // 80 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int KS = K >> 5;
+    const int KT = K >> 6;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
-    auto fsw = [](int q) { return (0x78 >> (2 * q)) & 3; };
     // the XCD's contiguous run of tiles, walked with stride gridDim.x / 8 (speed only)
     const int wg_x = gridDim.x >> 3, slot = (int)blockIdx.x >> 3;
     const int run_len = (n_tiles + 7) >> 3, run0 = ((int)blockIdx.x & 7) * run_len;
     const int per_x = run0 + run_len < n_tiles ? run_len : n_tiles - run0;
-    // fragment read offsets (16-byte chunks inside a stage): row c of m-tile / n-tile 0, k-chunk g
-    const int frag = c * 4 + (g ^ fsw(c >> 2));
-    // DMA: lane -> row lane / 4 of its piece, source chunk (lane % 4) ^ f(lane / 16)   [(row / 4) % 4 == lane / 16 inside a 16-row piece]
-    const int prow = lane >> 2, pch = (lane & 3) ^ fsw(lane >> 4);
+    // fragment reads: row c of a 16-row tile, chunk (ks * 4 + g) ^ (c & 7); DMA pieces of 8 rows: lane -> row lane / 8, chunk (lane % 8) ^ row
+    const int fr0 = c * 8 + (g ^ (c & 7)), fr1 = c * 8 + ((4 + g) ^ (c & 7));
+    const int lr = lane >> 3, lch = (lane & 7) ^ lr;
     for (int it = slot; it < per_x; it += wg_x) {
-        const int t = run0 + it;
+        int t = run0 + it;
+        asm volatile("" : "+s"(t));                           // (opaque: keeps the per-tile address arithmetic inside the tile loop)
         const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-        unsigned voa[4], vow[2];
+        unsigned voa[8], vow[4];                              // this wave's pieces: A rows (8 w + i) * 8 .., W rows (4 w + i) * 8 ..
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = (wave * 4 + i) * 16 + prow;
+        for (int i = 0; i < 8; ++i) {
+            int r = (wave * 8 + i) * 8 + lr;
             r = m0 + r < M ? r : M - 1 - m0;
-            voa[i] = (unsigned)(r * lda + pch * 8) * 2u;
+            voa[i] = (unsigned)(r * lda + lch * 8) * 2u;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int r = (wave * 2 + i) * 16 + prow;
+        for (int i = 0; i < 4; ++i) {
+            int r = (wave * 4 + i) * 8 + lr;
             r = n0 + r < N ? r : N - 1 - n0;
-            vow[i] = (unsigned)(r * ldw + pch * 8) * 2u;
+            vow[i] = (unsigned)(r * ldw + lch * 8) * 2u;
         }
         const char* abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
         const char* wbase = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw);
-        auto issue_step = [&](int j, int st) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                glds16_hidden_s(abase + j * 64, voa[i], lds_base + (unsigned)(st * STAGE + (wave * 4 + i) * 64) * 16u);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                glds16_hidden_s(wbase + j * 64, vow[i], lds_base + (unsigned)(st * STAGE + SA + (wave * 2 + i) * 64) * 16u);
+        auto issue_a = [&](int i, int kt, int st) {
+            glds16_hidden_s(abase + kt * 128, voa[i], lds_base + (unsigned)(st * SA + (wave * 8 + i) * 64) * 16u);
         };
-        // prologue: steps 0, 1, 2 in flight; step 0 landed and published; its fragments read outside the pipeline
-        issue_step(0, 0);
-        if (KS > 1) issue_step(1, 1);
-        if (KS > 2) issue_step(2, 2);
+        auto issue_w = [&](int i, int kt) {
+            glds16_hidden_s(wbase + kt * 128, vow[i], lds_base + (unsigned)(WOFF + (wave * 4 + i) * 64) * 16u);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_w(i, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_a(i, 0, 0);
         f32x4 acc[4][8];
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (KS > 2)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (KS > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // Fragments: W double-buffered (fw0 / fw1); A refilled IN PLACE -- the MFMAs run m-tile by m-tile, fa[m] is dead after its four
-        // MFMAs and is re-read for step j+1 right behind them -- except m-tiles 6 and 7, whose refill would be requested at the very end
-        // of the step and waited for at the top of the next: those two alternate between fa[6], fa[7] and the spare pair fs[0], fs[1],
-        // requested at the START of the step.  72 fragment registers instead of the 96 of a full double buffer (which spilled 23).
-        v8 fa[8], fs[2], fw0[4], fw1[4];
         auto rd = [&](const float4* p_) -> v8 { const float4 v = *p_; return *reinterpret_cast<const v8*>(&v); };
-        {
-            const float4* sa = lds + (wm * 128) * 4 + frag;
-            const float4* sw = lds + SA + (wn * 64) * 4 + frag;
+        for (int u = 0; u < KT; ++u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of A(u), W(u) (and, at u = 0, the previous tile's stores)
+            __builtin_amdgcn_s_barrier();                        // B1
+            const float4* sa = lds + (u & 1) * SA + (wm * 128) * 8;
+            const float4* sw = lds + WOFF + (wn * 64) * 8;
+            v8 fw[2][4], fa[8];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) fw0[n] = rd(sw + n * 64);
+            for (int n = 0; n < 4; ++n) { fw[0][n] = rd(sw + n * 128 + fr0); fw[1][n] = rd(sw + n * 128 + fr1); }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) fa[m] = rd(sa + m * 64);
-        }
-        // one step: 32 MFMAs on (fwc, fa[0..5], c6, c7); among them the 12 fragment reads of step j+1 (stage s1) into (fwn, fa[0..5], n6, n7)
-        // and this wave's six pieces of step j+3 into the stage step j has just vacated (s0)
-        auto step = [&](int j, int s0, int s1, v8 (&fwc)[4], v8 (&fwn)[4], v8& c6, v8& c7, v8& n6, v8& n7) {
-            // top: every read of step j's fragments is complete (stage s0 is consumed), this wave's pieces of step j+1 have landed
+            for (int m = 0; m < 8; ++m) fa[m] = rd(sa + m * 128 + fr0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (j + 2 < KS)      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (j + 1 < KS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            const bool nx = j + 1 < KS, dma = j + 3 < KS;
-            const float4* sa = lds + s1 * STAGE + (wm * 128) * 4 + frag;
-            const float4* sw = lds + s1 * STAGE + SA + (wn * 64) * 4 + frag;
-            if (nx) {
-                fwn[0] = rd(sw); fwn[1] = rd(sw + 64); fwn[2] = rd(sw + 128); fwn[3] = rd(sw + 192);
-                n6 = rd(sa + 6 * 64); n7 = rd(sa + 7 * 64);
-            }
+            __builtin_amdgcn_s_barrier();                        // B2: every wave holds W(u) in registers
+            const bool nx = u + 1 < KT;
+            const int st1 = (u + 1) & 1;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                if (dma && m < 6) {                           // pieces 0..3: A, 4..5: W
-                    if (m < 4) glds16_hidden_s(abase + (j + 3) * 64, voa[m], lds_base + (unsigned)(s0 * STAGE + (wave * 4 + m) * 64) * 16u);
-                    else       glds16_hidden_s(wbase + (j + 3) * 64, vow[m - 4], lds_base + (unsigned)(s0 * STAGE + SA + (wave * 2 + m - 4) * 64) * 16u);
-                }
+            for (int m = 0; m < 8; ++m) {                        // k-step 0
+                if (nx) issue_a(m, u + 1, st1);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const v8 av = m == 6 ? c6 : (m == 7 ? c7 : fa[m]);
-                    acc[n][m] = X16<T>::mfma(fwc[n], av, acc[n][m]);
-                }
-                if (nx && m < 6) fa[m] = rd(sa + m * 64);      // in place, behind its last use
+                for (int n = 0; n < 4; ++n) acc[n][m] = X16<T>::mfma(fw[0][n], fa[m], acc[n][m]);
+                fa[m] = rd(sa + m * 128 + fr1);                   // k-step 1's fragment, in place behind the last use
                 __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        {
-            int s0 = 0, s1 = 1;
-            for (int j = 0; j < KS; j += 2) {                 // (K % 64 == 0: an even number of steps)
-                step(j, s0, s1, fw0, fw1, fa[6], fa[7], fs[0], fs[1]);
-                s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
-                step(j + 1, s0, s1, fw1, fw0, fs[0], fs[1], fa[6], fa[7]);
-                s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {                        // k-step 1
+                if (nx && m < 4) issue_w(m, u + 1);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n][m] = X16<T>::mfma(fw[1][n], fa[m], acc[n][m]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // epilogue: the tile as bf16 through the ring (row pitch 256 B, 16-byte chunk XOR-swizzled by the row), whole-row stores
+        // epilogue: the tile as bf16 through the two A stages (row pitch 256 B, 16-byte chunk XOR-swizzled by the row), whole-row stores
         __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
         unsigned char* sC = reinterpret_cast<unsigned char*>(lds);
         int tid_o = tid, c_o = c, g_o = g;                    // opaque per-tile copies: hipcc otherwise computes every epilogue address
@@ -1334,14 +1311,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_duo_kernel(const T* __restrict_
             if (grow < M && gcol < N) *reinterpret_cast<u32x4*>(C + (int64_t)grow * ldc + gcol) = vw;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                         // the ring is free for the next tile's first pieces
+        __builtin_amdgcn_s_barrier();                         // the stages are free for the next tile's first pieces
     }
 }
 
 template <int EPI, typename T>
 static int launch_duo(const T* a, int lda, const T* w, int ldw, const float* bias, const T* r, T* c, int ldc, int M,
                       int N, int K, hipStream_t st) {
-    const int shmem = 3 * (256 + 128) * 64;             // 72 KB: two workgroups per CU
+    const int shmem = 2 * 256 * 128 + 128 * 128;        // 80 KB: two workgroups per CU
     DeviceInfo di;
     MGEA_TRY(device_info(&di));
     static uint64_t attr_done = 0;
@@ -1394,7 +1371,7 @@ template <int EPI>
 static int launch_glds_pick(const bf16_t* a, int lda, const bf16_t* w, int ldw, const float* bias, const bf16_t* r, bf16_t* c,
                             int ldc, int M, int N, int K, hipStream_t st, GemmBf16Info* info) {
     const int force = tune(TUNE_BF16_GEMM_TILE);   // 1: 128x128 / 2: 256x128 / 3: 256x256 ring kernels (tools/gemm_bf16_bench.py)
-    if (force == 5 && EPI != BEPI_BIAS_RES && K % 32 == 0 && N % 8 == 0) {   // (prototype switch: the two-workgroups-per-CU kernel)
+    if (force == 5 && EPI != BEPI_BIAS_RES && K % 64 == 0 && N % 8 == 0) {   // (prototype switch: the two-workgroups-per-CU kernel)
         if (info) { info->kernel = 3; info->half_tiles = 0; }
         return launch_duo<EPI, bf16_t>(a, lda, w, ldw, bias, r, c, ldc, M, N, K, st);
     }

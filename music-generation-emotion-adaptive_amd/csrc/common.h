@@ -230,7 +230,8 @@ int launch_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st, i
 //                   from which launch_ln_rowstat makes the next (mean, rstd).
 struct BfEpiLn { const float* rowstat; const float* c1; const float* ln_g; const float* ln_b; float* stats_out; };
 // What a launch_gemm_bf16 call ran (optional out-parameter; the engines count these for mgea_bert_stats): kernel 0 = the
-// register-staged 128 x 128 kernel, 1 = a ring kernel, 2 = the persistent phase-interleaved 256 x 256 kernel; half_tiles = 1 when that
+// register-staged 128 x 128 kernel, 1 = a ring kernel, 2 = the persistent phase-interleaved 256 x 256 kernel, 3 = the two-workgroups-per-CU
+// 256 x 128 kernel (switch bf16_gemm_tile = 5 only); half_tiles = 1 when the persistent
 // kernel cuts the tiles left over after its full rounds into two 128-row halves (bf16.hip, "HALF-TILE TAIL").
 // reverse (IN): ask the persistent kernel to walk its tiles from the end of every XCD's run (switch bf16_gemm_reverse; for a GEMM whose A
 // operand is the previous kernel's large output: see the kernel).

@@ -62,6 +62,37 @@ def test_gemm_bf16_phase_interleaved_kernel(M, N, K, mode, tune):
         assert float((err / (want.abs() + 1.0)).max()) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1000, 512, 128), (768, 768, 3072), (2048, 2304, 768), (1300, 3072, 192), (33000, 1152, 320)])
+@pytest.mark.parametrize("mode", ["bias", "gelu"])
+def test_gemm_bf16_two_workgroups_per_cu_kernel(M, N, K, mode, tune):
+    """The two-workgroups-per-CU kernel (256 x 128 per 4-wave workgroup, two A stages + one W buffer in 80 KB, switch
+    bf16_gemm_tile = 5; measured, not the engine's choice): one K-tile, two, odd counts, many; ragged M; more tiles than slots (several
+    tiles per workgroup: the ring and the C stage are reused); N not a multiple of 256.  Every element against fp64 math on the same
+    bf16 inputs, twice, and BITWISE equal to the persistent 256 x 256 kernel (the same MFMA sequence over K for every element)."""
+    from mgea import ops
+    a = rnd(M, K, seed=31).bfloat16()
+    w = rnd(N, K, seed=32, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=33)
+    want = a.double() @ w.double().t() + b.double()
+    if mode == "gelu":
+        want = torch.nn.functional.gelu(want)
+    ac, wc, bc = a.cuda(), w.cuda(), b.cuda()
+    tune("bf16_gemm_tile", 5)
+    outs = []
+    for _ in range(2):
+        info = []
+        got = ops.gemm_bf16(ac, wc, bc, gelu=(mode == "gelu"), info=info)
+        assert info[0] == 3                                        # the two-workgroups-per-CU kernel ran
+        outs.append(got)
+        err = (got.cpu().double() - want).abs()
+        assert float((err / (want.abs() + 1.0)).max()) < 6e-3
+    assert torch.equal(outs[0], outs[1])
+    tune("bf16_gemm_tile", 4)
+    info = []
+    ref = ops.gemm_bf16(ac, wc, bc, gelu=(mode == "gelu"), info=info)
+    assert info[0] == 2 and torch.equal(ref, outs[0])
+
+
 def _ln_tables(M, K, seed):
     """row statistics of a [M, K] bf16 matrix as the pipeline carries them: (mean, rstd) in fp32"""
     g = torch.Generator().manual_seed(seed)
