@@ -10,7 +10,9 @@ from mgea import _lib, ops
 
 old = _lib.tune_get("bf16_gemm_tile")
 for name, M, N, K, epi in [("qkv0", 32768, 2304, 768, 0), ("fc1g", 32768, 3072, 768, 1), ("out0", 32768, 768, 768, 0), ("fc2_0", 32768, 768, 3072, 0),
-                           ("rag", 5000, 2304, 192, 0), ("sq4k", 4096, 4096, 4096, 0), ("sq8k", 8192, 8192, 8192, 0)]:
+                           ("rag", 5000, 2304, 192, 0), ("sq4k", 4096, 4096, 4096, 0), ("sq8k", 8192, 8192, 8192, 0),
+                           # Decoder-S prefill [64, 1024] (fp16 there; the bf16 kernels run at the same rate): K = 512 is 8 K-tiles per tile
+                           ("dSqkv", 65536, 1536, 512, 0), ("dSfc1", 65536, 2048, 512, 1), ("dSout", 65536, 512, 512, 0), ("dSfc2", 65536, 512, 2048, 0)]:
     a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     b = torch.randn(N, device="cuda")
     kw = dict(gelu=epi == 1, out=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"))
