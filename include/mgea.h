@@ -187,7 +187,9 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
 /* What the handle ran (so that a test can assert WHICH kernels produced the numbers it checks): out[0] forwards so far; of the
  * last forward: [1] 1 = folded-LayerNorm bf16 pipeline, [2] / [3] / [4] bf16 GEMM launches on the persistent 256 x 256 kernel /
  * a ring kernel / the 128 x 128 kernel, [5] persistent launches that cut their left-over tiles into 128-row halves,
- * [6] LayerNorm kernel launches, [8 + e] bf16 GEMM launches with epilogue e (0..5); others 0. */
+ * [6] LayerNorm kernel launches, [7] 1 when the last layer ran for the [CLS] rows only (K | V of every position, the rest on B rows:
+ * the classifier reads nothing else; switch bert_full_last_layer = 1 computes every position), [8 + e] bf16 GEMM launches with
+ * epilogue e (0..5); others 0. */
 int mgea_bert_stats(mgea_bert* h, int64_t* out /* [16] */);
 
 /* W[out,in] += scale * B[out,r] @ A[r,in] in place (peft LoRA fold, W' = W + (alpha/r) B A;

@@ -66,7 +66,7 @@ struct mgea_bert {
     void *wb = nullptr, *hb = nullptr, *qkvb = nullptr, *ctxb = nullptr, *ffnb = nullptr, *tmpb = nullptr;  // bf16 mode
     // what the last forward ran (mgea_bert_stats): forwards so far; folded-LayerNorm pipeline or not; bf16 GEMM launches by kernel
     // (persistent / ring / small), persistent launches that cut their tail tiles in halves, by epilogue (0..5); LayerNorm kernels
-    int64_t n_forwards = 0, last_fold = 0, last_persistent = 0, last_ring = 0, last_small = 0, last_half_tiles = 0, last_ln_kernels = 0;
+    int64_t n_forwards = 0, last_fold = 0, last_persistent = 0, last_ring = 0, last_small = 0, last_half_tiles = 0, last_ln_kernels = 0, last_cls_only = 0;
     int64_t last_epi[6] = {0, 0, 0, 0, 0, 0};
     // bf16 mode, folded-LayerNorm pipeline (big batches: every GEMM on the persistent kernel): W diag(gamma) copies, c1 / c2 vectors,
     // per-tile row sums and the two (mean, rstd) tables
@@ -197,6 +197,33 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         return MGEA_OK;
     };
     int Sk = 1;
+    // LAST LAYER, [CLS] ROWS ONLY.  The classifier reads hidden_state[:, 0] of the last layer and nothing else of it
+    // (emotion_analysis/modeling.py:14-21 -> DistilBertForSequenceClassification), so of that layer only the keys and values of every
+    // position are needed (the [CLS] query attends to them); its query, attention, out-projection, both LayerNorms and the FFN are
+    // computed for the B [CLS] rows, in fp32 on the arena's fp32 matrices in both modes (like the classifier head).  Same function of
+    // the inputs as computing every position and discarding all but one -- 1 / n_layers of the forward less about 2 / 3 of a QKV GEMM
+    // (switch bert_full_last_layer = 1 computes every position; both are tested against the goldens).  The [B, 2 D + hidden] fp32
+    // scratch is the FFN buffer, idle in that layer.
+    const int64_t cls_cap = c.dtype == MGEA_DTYPE_BF16 ? (int64_t)c.max_tokens * Hd / 2 : (int64_t)c.max_tokens * Hd;   // floats in ffnb / ffn
+    bool cls_last = !tune(TUNE_BERT_FULL_LAST_LAYER) && S >= 4 && (int64_t)B * (2 * D + Hd) <= cls_cap;
+    const int last = c.n_layers - 1;
+    auto cls_tail = [&](int l, const void* kv, int kv_bf16) -> int {   // pooled [B, D] = the layer's input rows at [CLS]; kv = qkv buffer with K | V filled
+        float* cls = reinterpret_cast<float*>(c.dtype == MGEA_DTYPE_BF16 ? h->ffnb : (void*)h->ffn);
+        float *cq = cls, *cctx = cls + (int64_t)B * D, *chid = cls + (int64_t)2 * B * D;
+        MGEA_TRY(gemm(h->pooled, D, h->lw(l, BL_QKVW), B, D, D, &Sk));                     // q = x W_q^T + b_q (rows 0..D-1 of the stacked matrix)
+        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_QKVB), cq, D, B, D, ACT_NONE, st));
+        MGEA_TRY(launch_attn_cls(cq, kv, kv_bf16, mask_dev, cctx, B, S, c.n_heads, dh, st));
+        MGEA_TRY(gemm(cctx, D, h->lw(l, BL_OUTW), B, D, D, &Sk));
+        MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->pooled, nullptr,
+                                    h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, B, D, 1, st));
+        MGEA_TRY(gemm(h->pooled, D, h->lw(l, BL_L1W), B, Hd, D, &Sk));
+        MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, Hd), (int)slab_ld(Hd), h->lw(l, BL_L1B), chid, Hd, B, Hd, ACT_GELU, st));
+        MGEA_TRY(gemm(chid, Hd, h->lw(l, BL_L2W), B, D, Hd, &Sk));
+        MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->pooled, nullptr,
+                                    h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, B, D, 1, st));
+        return MGEA_OK;
+    };
+    h->last_cls_only = 0;
     if (c.dtype == MGEA_DTYPE_BF16) {
         // perf mode: bf16 MFMA GEMMs with fused bias / GELU / residual epilogues, bf16 flash attention
         auto wb = [&](int l, int j) { return (const void*)h->wbf(h->off[B_HEAD0 + l * BL_COUNT + j]); };
@@ -222,11 +249,27 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         const bool fold = !tune(TUNE_BERT_BF16_NOFOLD) && D % 256 == 0 && Hd % 256 == 0 && gemm_bf16_is_persistent(M, 3 * D, D) && gemm_bf16_is_persistent(M, D, D) &&
                           gemm_bf16_is_persistent(M, Hd, D) && gemm_bf16_is_persistent(M, D, Hd);
         h->last_fold = fold ? 1 : 0;
+        if (fold && cls_last && !gemm_bf16_is_persistent(M, 2 * D, D)) cls_last = false;   // (the K | V GEMM must stay on the kernel with the folding epilogue)
+        h->last_cls_only = cls_last ? 1 : 0;
+        const int64_t kv_off = (int64_t)D * D * 2;          // bytes: rows D.. of a stacked bf16 [3 D, D] matrix
         if (fold) {
             const int npart = D / 256;
             const float *id_g = h->ident + (int64_t)c.max_tokens * 2, *id_b = id_g + D;
             for (int l = 0; l < c.n_layers; ++l) {
                 const bool first = l == 0;
+                if (cls_last && l == last) {                // K | V of every position, the rest of the layer on the [CLS] rows
+                    if (first) {
+                        MGEA_TRY(bgemm(h->hb, D, (const char*)wb(l, BL_QKVW) + kv_off, D, h->lw(l, BL_QKVB) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M,
+                                       2 * D, D, 0));
+                        MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+                    } else {
+                        BfEpiLn q{h->rowstat_out, h->qkvc(l, 0) + D, nullptr, nullptr, nullptr};
+                        MGEA_TRY(bgemm(h->hb, D, h->qkvf(l) + kv_off, D, h->qkvc(l, 1) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M, 2 * D, D, 3, &q));
+                        MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(l - 1, BL_OLNW), h->lw(l - 1, BL_OLNB), h->pooled, B, S, D, st));
+                    }
+                    MGEA_TRY(cls_tail(l, h->qkvb, 1));
+                    break;
+                }
                 if (first) {
                     MGEA_TRY(bgemm(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0));
                 } else {
@@ -246,10 +289,18 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
                 MGEA_TRY(bgemm(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->tmpb, h->hb, D, M, D, Hd, 5, &f2));
                 MGEA_TRY(launch_ln_rowstat(h->stats_part, h->rowstat_out, M, npart, D, c.ln_eps, st));
             }
-            MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(c.n_layers - 1, BL_OLNW), h->lw(c.n_layers - 1, BL_OLNB), h->pooled, B, S,
-                                               D, st));
+            if (!cls_last)
+                MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(c.n_layers - 1, BL_OLNW), h->lw(c.n_layers - 1, BL_OLNB), h->pooled, B, S,
+                                                   D, st));
         } else {
         for (int l = 0; l < c.n_layers; ++l) {
+            if (cls_last && l == last) {
+                MGEA_TRY(bgemm(h->hb, D, (const char*)wb(l, BL_QKVW) + kv_off, D, h->lw(l, BL_QKVB) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M, 2 * D,
+                               D, 0));
+                MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+                MGEA_TRY(cls_tail(l, h->qkvb, 1));
+                break;
+            }
             MGEA_TRY(bgemm(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0));
             MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
             MGEA_TRY(bgemm(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2));
@@ -259,12 +310,25 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             MGEA_TRY(bgemm(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
         }
-        MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+        if (!cls_last) MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
         }
     } else {
+    h->last_cls_only = cls_last ? 1 : 0;
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
                                   D, c.vocab, st));
     for (int l = 0; l < c.n_layers; ++l) {
+        if (cls_last && l == last) {               // K | V of every position (columns D.. of the stacked projection), the rest on the [CLS] rows
+            const float *wkv = h->lw(l, BL_QKVW) + (int64_t)D * D, *bkv = h->lw(l, BL_QKVB) + D;
+            if (gemm_direct_epilogue_ok(M, 2 * D)) {
+                MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, wkv, D, bkv, h->qkv + D, 3 * D, M, 2 * D, D, ACT_NONE, st));
+            } else {
+                MGEA_TRY(gemm(h->h, D, wkv, M, 2 * D, D, &Sk));
+                MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 2 * D), (int)slab_ld(2 * D), bkv, h->qkv + D, 3 * D, M, 2 * D, ACT_NONE, st));
+            }
+            MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+            MGEA_TRY(cls_tail(l, h->qkv, 0));
+            break;
+        }
         if (gemm_direct_epilogue_ok(M, 3 * D)) {   // bias (+ GELU below) inside the GEMM epilogue: no slab round trip
             MGEA_TRY(launch_gemm_f32_bias_act(h->h, D, h->lw(l, BL_QKVW), D, h->lw(l, BL_QKVB), h->qkv, 3 * D, M, 3 * D, D,
                                               ACT_NONE, st));
@@ -288,7 +352,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->h, nullptr,
                                     h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, M, D, 1, st));
     }
-    MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+    if (!cls_last) MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
     }
     // pooled = h[:, 0]  ->  pre_classifier -> ReLU -> classifier (fp32 in both modes)
     MGEA_TRY(gemm(h->pooled, D, h->hw(0), B, D, D, &Sk));
@@ -305,7 +369,7 @@ int mgea_bert_stats(mgea_bert* h, int64_t* out) {
     std::lock_guard<std::mutex> lk(h->mu);
     for (int i = 0; i < 16; ++i) out[i] = 0;
     out[0] = h->n_forwards; out[1] = h->last_fold; out[2] = h->last_persistent; out[3] = h->last_ring; out[4] = h->last_small;
-    out[5] = h->last_half_tiles; out[6] = h->last_ln_kernels;
+    out[5] = h->last_half_tiles; out[6] = h->last_ln_kernels; out[7] = h->last_cls_only;
     for (int e = 0; e < 6; ++e) out[8 + e] = h->last_epi[e];
     return MGEA_OK;
 }

@@ -46,6 +46,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BF16_GEMM_PHASES,     // whole tiles of the persistent kernel: 4 phases of 16 MFMAs per K-tile, 2 (default) phases of 32, or 1 = software-pipelined, one barrier per K-tile
        TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
+       TUNE_BERT_FULL_LAST_LAYER, // 1: the last DistilBERT layer computes every position (as the reference does) instead of K | V for all + the rest for the [CLS] rows only
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
        TUNE_ATTN16_WIDE,          // 16-bit flash attention with 8 waves / 256-key stages: 0 never, 1 from 512 tokens on (default), 2 always
        TUNE_DECODER_PREFILL16_OVERLAP,   // 1 (default): the KV scatter of the fp16 prefill runs on a side stream under the attention kernel
@@ -191,6 +192,8 @@ struct StepState {
     const SamplerParams* params;   // device record whose eos_id wins (NULL: eos_id above)
     __host__ __device__ int eos() const { return params ? params->eos_id : eos_id; }
 };
+// one query per sequence (the [CLS] position, fp32 q [B, D]) against the K | V columns of a packed qkv buffer [B * S, 3 D] (fp32 or bf16) -> fp32 [B, D]
+int launch_attn_cls(const float* q, const void* qkv, int qkv_bf16, const int32_t* mask, float* out, int B, int S, int H, int dh, hipStream_t st);
 int launch_logits_argmax(const float* P, int S, int64_t ps, int ldp, const float* bias, float* logits,
                          int M, int V, int32_t* argmax_out, hipStream_t st);
 // sampler over logits [B,V] (top_k != 1); writes ids[b]; probs_out optional

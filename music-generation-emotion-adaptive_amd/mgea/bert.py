@@ -207,7 +207,8 @@ class BertEngine:
         out = (C.c_int64 * 16)()
         check(self.lib.mgea_bert_stats(self.h, out))
         return dict(forwards=out[0], folded_layernorm=bool(out[1]), gemm_persistent=out[2], gemm_ring=out[3], gemm_small=out[4],
-                    gemm_half_tile_tails=out[5], layernorm_kernels=out[6], gemm_by_epilogue=[int(out[8 + e]) for e in range(6)])
+                    gemm_half_tile_tails=out[5], layernorm_kernels=out[6], last_layer_cls_only=bool(out[7]),
+                    gemm_by_epilogue=[int(out[8 + e]) for e in range(6)])
 
     def forward(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, want_logits=True, want_argmax=True):
         """ids [B,S] (any int dtype), mask [B,S] 0/1 -> (logits [B,labels] fp32, argmax [B] int32)."""

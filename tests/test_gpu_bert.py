@@ -18,10 +18,15 @@ def make(g, with_adapter=True):
 
 
 @pytest.mark.parametrize("tag", ["tiny", "base"])
-def test_logits_and_labels_vs_golden(golden, tag):
+@pytest.mark.parametrize("full_last", [0, 1])
+def test_logits_and_labels_vs_golden(golden, tag, full_last, tune):
+    """Both forms of the last layer against the transformers-generated golden: [CLS] rows only (the engine's default: K | V of every
+    position, query / attention / out-proj / FFN for the B rows the classifier reads) and every position (as the reference computes it)."""
+    tune("bert_full_last_layer", full_last)
     g = golden("distilbert_" + tag)
     eng = make(g)
     logits, amax = eng.forward(torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]))
+    assert eng.stats()["last_layer_cls_only"] == (not full_last)
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-3, rtol=0)
     assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4
     assert amax.cpu().tolist() == g["argmax"].tolist()
@@ -47,3 +52,28 @@ def test_sequence_longer_than_position_table(golden):
     eng = make(g)
     with pytest.raises(RuntimeError):
         eng.forward(torch.zeros(1, 33, dtype=torch.long), None)
+
+
+@pytest.mark.parametrize("dim,n_heads,S", [(128, 4, 200), (128, 2, 77), (256, 4, 513), (64, 2, 4)])
+def test_last_layer_on_cls_rows_only_equals_every_position(dim, n_heads, S, tune):
+    """The [CLS]-rows-only last layer against the same engine computing every position: head_dim 32 and 64, sequence lengths that are
+    not a multiple of the 64-key chunks of the one-query attention kernel (and one longer than a chunk's eight-fold), ragged key
+    masks.  Same function of the inputs; the GEMMs of 5 rows instead of 5 x S take another split of K, so equality is to fp32
+    rounding, not bitwise."""
+    from mgea.bert import BertEngine
+    B, vocab, L = 5, 500, 2
+    sd = synth.distilbert_state_dict(17, vocab, 520, dim, L, 4 * dim)
+    ids = torch.from_numpy(synth.integers(17, "ids", (B, S), 0, vocab))
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b in range(1, B):
+        mask[b, max(1, S - (S // 6) * b):] = 0
+    out = {}
+    for full_last in (0, 1):
+        tune("bert_full_last_layer", full_last)
+        eng = BertEngine(sd, n_heads=n_heads, max_tokens=B * S)
+        logits, amax = eng.forward(ids, mask)
+        assert eng.stats()["last_layer_cls_only"] == (not full_last)
+        out[full_last] = (logits.cpu().numpy(), amax.cpu().numpy())
+        eng.close()
+    assert np.abs(out[0][0] - out[1][0]).max() < 2e-5
+    assert (out[0][1] == out[1][1]).all()

@@ -369,7 +369,9 @@ def _bert_logits(sd, n_heads, ids, mask, tune, fold):
     logits, amax = eng.forward(ids, mask)
     st = eng.stats()
     assert st["folded_layernorm"] == fold and st["gemm_ring"] == 0 and st["gemm_small"] == 0
-    assert st["layernorm_kernels"] == (0 if fold else 2 * len([k for k in sd if k.endswith("sa_layer_norm.weight")]))
+    n_layers = len([k for k in sd if k.endswith("sa_layer_norm.weight")])
+    assert st["last_layer_cls_only"]                          # (the last layer's two LayerNorms run on the [CLS] rows, in its fp32 tail)
+    assert st["layernorm_kernels"] == (0 if fold else 2 * (n_layers - 1))
     eng.close()
     return logits.cpu().numpy(), amax.cpu().numpy()
 
@@ -403,7 +405,8 @@ def test_bert_bf16_folded_layernorm_pipeline(tune):
           f"folded vs unfolded {np.abs(folded - plain).max():.4f}")
 
 
-def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden):
+@pytest.mark.parametrize("full_last", [0, 1])
+def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden, full_last, tune):
     """BASELINE configs[1] as bench.py times it: DistilBERT-base (+ merged LoRA), bf16, [256, 128] ids with padding, the ENGINE'S OWN
     dispatch (no switch set): folded-LayerNorm pipeline, QKV / FC1 / out-proj / FC2 on the persistent kernel with epilogues
     3 / 4 / 5 / 5 (layer 0's QKV: 0), half-tile tails on the N = 768 and N = 2304 GEMMs -- asserted from mgea_bert_stats, not
@@ -411,6 +414,7 @@ def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden):
     tests/test_gpu_bert.py) within the bf16 tolerance, labels equal wherever the f32 top-2 gap exceeds twice that; rows 0..7 are
     the golden fixture's own inputs and are compared with ITS logits (emotion_analysis/inference.py:16-20 / modeling.py:14-21)."""
     from mgea.bert import BertEngine
+    tune("bert_full_last_layer", full_last)     # 0 (default): the last layer's K | V for every position, the rest of it for the 256 [CLS] rows (fp32)
     g = golden("distilbert_base")
     seed, vocab, max_pos, dim, n_heads, n_layers, hidden, gb, seq = (int(x) for x in g["cfg"])
     B, S = 256, 128
@@ -431,9 +435,11 @@ def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden):
     logits2, _ = eng.forward(ids, mask)
     eng.close()
     assert st["folded_layernorm"] and st["layernorm_kernels"] == 0 and st["gemm_ring"] == 0 and st["gemm_small"] == 0
-    assert st["gemm_persistent"] == 4 * n_layers
-    assert st["gemm_by_epilogue"] == [1, 0, 0, n_layers - 1, n_layers, 2 * n_layers]
-    assert st["gemm_half_tile_tails"] == 3 * n_layers              # QKV (4.5 rounds), out-proj and FC2 (1.5 rounds); FC1 is 6 whole rounds
+    assert st["last_layer_cls_only"] == (not full_last)
+    nl = n_layers if full_last else n_layers - 1                    # layers whose out-proj / FC1 / FC2 run on all 32768 rows
+    assert st["gemm_persistent"] == 4 * nl + (0 if full_last else 1)            # + the last layer's K | V GEMM (N = 1536: three whole rounds)
+    assert st["gemm_by_epilogue"] == [1, 0, 0, n_layers - 1, nl, 2 * nl]
+    assert st["gemm_half_tile_tails"] == 3 * nl                     # QKV (4.5 rounds), out-proj and FC2 (1.5 rounds); FC1 is 6 whole rounds
     assert torch.equal(logits, logits2)                             # deterministic: no atomics, no exchange
     logits, amax = logits.cpu().numpy(), amax.cpu().numpy()
     TOL = 0.08

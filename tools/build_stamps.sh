@@ -8,7 +8,7 @@ ABL=${1:-0}
 SUF=""; [ "$ABL" != "0" ] && SUF="_a$ABL"
 cd "$(dirname "$0")/../music-generation-emotion-adaptive_amd/csrc"
 mkdir -p build_stamps
-for f in capi gemm_f32 gemm_skinny gemv_small bf16 rowops attn_paged attn_dense sampler decoder bert; do
+for f in capi gemm_f32 gemm_skinny gemv_small bf16 rowops attn_paged attn_dense attn_cls sampler decoder bert; do
   if [ $f = bf16 ] || [ ! -f build/$f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DMGEA_PH_STAMPS -DMGEA_PH_ABLATE=$ABL -c $f.hip -o build_stamps/$f.o
   else

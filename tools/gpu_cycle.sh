@@ -19,6 +19,7 @@ run() {  # run <name> <seconds> <cmd...>
 for s in $STEPS; do
   case $s in
     bf16tests) run bf16tests 900 python3 -m pytest tests/test_gpu_bf16.py -x -q -m gpu -s || exit 1 ;;
+    berttests) run berttests 900 python3 -m pytest tests/test_gpu_bert.py tests/test_gpu_bf16.py tests/test_gpu_dropin.py tests/test_gpu_loaders.py tests/test_gpu_api_shim.py -x -q -m gpu || exit 1 ;;
     alltests)  run alltests 1100 python3 -m pytest tests -x -q -m gpu || exit 1 ;;
     gemmbench) run gemmbench 300 python3 tools/gemm_bf16_bench.py || exit 1 ;;
     phasesab)  run phasesab 300 python3 tools/gemm_bf16_phases_ab.py || exit 1 ;;
