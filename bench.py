@@ -266,8 +266,15 @@ def prefill_extra(arena, device, B=64, T=1024, reps=5, dtype="f32"):
         del lg
         dt = sorted(times)[len(times) // 2]
         flops = 2 * B * T * (NL * 12 * C_ * C_ + (V * C_ if want_logits else 0)) + 4 * B * T * T * C_ * NL
+        if not want_logits:
+            # a forward whose logits are dropped (the prompt prefill of sample_kvcache, api_cache.py:163) ends once the last block's
+            # K | V are in the cache: its query projection, attention, out-projection and MLP (10 of its 12 C^2 and its T^2 term)
+            # are not executed, and are not counted
+            flops -= 2 * B * T * (10 if dtype == "f16" else 9) * C_ * C_ + 4 * B * T * T * C_   # (the exact-fp32 path still projects that block's query)
         out[name] = dict(ms=dt * 1e3, tokens_per_sec=B * T / dt, tflops=flops / dt / 1e12, algorithmic_tflop=flops / 1e12,
                          frac_of_mfma_peak=flops / dt / 1e12 / peak, ms_each=[round(t * 1e3, 2) for t in times])
+        if not want_logits:
+            out[name]["note"] = "logits dropped: the last block stops at its K | V (FLOPs executed; switch decoder_prefill_full = 1 runs the whole block)"
     st = eng.stats()
     eng.close()
     w = out["with_logits"]

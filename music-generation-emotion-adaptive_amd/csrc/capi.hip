@@ -30,6 +30,7 @@ const TuneEntry kTune[] = {
     {TUNE_BF16_GEMM_PHASES, "bf16_gemm_phases", "MGEA_BF16_GEMM_PHASES", 2},
     {TUNE_BF16_GEMM_REVERSE, "bf16_gemm_reverse", "MGEA_BF16_GEMM_REVERSE", 1},
     {TUNE_BERT_BF16_NOFOLD, "bert_bf16_nofold", "MGEA_BERT_BF16_NOFOLD", 0},
+    {TUNE_DECODER_PREFILL_FULL, "decoder_prefill_full", "MGEA_DECODER_PREFILL_FULL", 0},
     {TUNE_BERT_FULL_LAST_LAYER, "bert_full_last_layer", "MGEA_BERT_FULL_LAST_LAYER", 0},
     {TUNE_DECODER_UNFUSED, "decoder_unfused", "MGEA_DECODER_UNFUSED", 0},
     {TUNE_DECODER_NOGEMV, "decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},

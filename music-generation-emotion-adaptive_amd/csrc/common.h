@@ -46,6 +46,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BF16_GEMM_PHASES,     // whole tiles of the persistent kernel: 4 phases of 16 MFMAs per K-tile, 2 (default) phases of 32, or 1 = software-pipelined, one barrier per K-tile
        TUNE_BF16_GEMM_REVERSE,    // 1 (default): the FFN down-projection walks its tiles from the end of each XCD's run (A = the up-projection's output)
        TUNE_BERT_BF16_NOFOLD,     // 1: bf16 DistilBERT with LayerNorm kernels instead of the folded-LayerNorm pipeline
+       TUNE_DECODER_PREFILL_FULL, // 1: a decoder forward whose logits are dropped still runs the whole last block (default: it stops at that block's K | V)
        TUNE_BERT_FULL_LAST_LAYER, // 1: the last DistilBERT layer computes every position (as the reference does) instead of K | V for all + the rest for the [CLS] rows only
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
        TUNE_ATTN16_WIDE,          // 16-bit flash attention with 8 waves / 256-key stages: 0 never, 1 from 512 tokens on (default), 2 always

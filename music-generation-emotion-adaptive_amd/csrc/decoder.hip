@@ -269,8 +269,10 @@ int gemm(mgea_decoder* h, const float* A, int lda, const float* W, int M, int N,
 
 // The NL blocks over M = B*T rows.  use_cache_attn: attention over the paged cache (decode /
 // extend); otherwise dense attention inside the qkv buffer (prefill with empty cache, twin mode).
+// kv_only_last: the caller drops the logits (the prompt prefill of sample_kvcache, api_cache.py:163: `_, past = model(idx)`), so nothing
+// reads the last block's output: once its K | V are in the cache the pass is over -- no attention, out-projection or MLP for that block.
 int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cache_attn, bool scatter,
-               hipStream_t st) {
+               hipStream_t st, bool kv_only_last = false) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, M = B * T;
     const bool post = c.block_mode == MGEA_BLOCK_POSTLN_RELU;
@@ -287,6 +289,7 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
             PROF(PC_ROWOP, launch_bias_act(h->slabs, S, slab_floats(M, 3 * C), (int)slab_ld(3 * C), h->lw(l, L_INB), h->qkv,
                                      3 * C, M, 3 * C, ACT_NONE, st));
         }
+        if (kv_only_last && scatter && l + 1 == c.n_layer) break;
         if (use_cache_attn) {
             PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T,
                                        C, 0, st));
@@ -352,7 +355,8 @@ bool gemv_ok(const mgea_decoder* h, int M, int T, const int32_t* lens, bool use_
            gemv_shape_ok(M, c.d_model, c.d_ff);
 }
 
-int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st) {
+int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t* lens, bool use_cache_attn, hipStream_t st,
+                     bool kv_only_last = false) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, M = B * T;
     const bool gv = gemv_ok(h, M, T, lens, use_cache_attn);
@@ -373,6 +377,7 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         } else {
             PROF(PC_GEMM, launch_skinny(EPI_QKV, a, st));
         }
+        if (kv_only_last && l + 1 == c.n_layer) break;       // (run_blocks: the logits are dropped, the last block's K | V are appended)
         if (use_cache_attn) {
             PROF(PC_ATTN_PAGED, launch_attn_paged(u.qkv, h->kv, l, u.page_table, h->max_pages, u.ctx_len, lens, u.att, B, T, C, 1, st));
         } else {
@@ -658,7 +663,7 @@ int ensure_p16(mgea_decoder* h, int64_t M, hipStream_t st) {
     return MGEA_OK;
 }
 
-int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, int T, float* logits_out, hipStream_t st) {
+int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, int T, float* logits_out, hipStream_t st, bool kv_only_last) {
     const auto& c = h->cfg;
     const int C = c.d_model, F = c.d_ff, V = c.vocab, M = B * T, npart = C / 256;
     MGEA_TRY(ensure_p16(h, M, st));
@@ -678,6 +683,14 @@ int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int 
     }
     for (int l = 0; l < c.n_layer; ++l) {
         const bool last = l + 1 == c.n_layer;
+        if (last && kv_only_last) {
+            // the logits are dropped (run_blocks): of the last block only K | V -- rows C.. of the stacked projection -- then its scatter
+            const BfEpiLn qk{p.rowstat, h->p16_vec(l, 0) + C, nullptr, nullptr, nullptr};
+            PROF(PC_GEMM, launch_gemm_bf16(xc, C, (const char*)h->p16_w(4 * l + 0) + (int64_t)C * C * 2, C, h->p16_vec(l, 1) + C, nullptr,
+                                           (char*)p.qkv + (int64_t)C * 2, 3 * C, M, 2 * C, C, 3, st, nullptr, &qk, 1));
+            PROF(PC_ROWOP, launch_kv_scatter_f16(p.qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, B, T, C, st));
+            break;
+        }
         const BfEpiLn q{p.rowstat, h->p16_vec(l, 0), nullptr, nullptr, nullptr};
         PROF(PC_GEMM, launch_gemm_bf16(xc, C, h->p16_w(4 * l + 0), C, h->p16_vec(l, 1), nullptr, p.qkv, 3 * C, M, 3 * C, C, 3, st, nullptr, &q, 1));
         if (overlap) {
@@ -751,17 +764,18 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     MGEA_TRY(ensure_ws(h, M));
     const bool cache_attn = (!post) && h->host_max_len > 0;
     const bool p16 = !fused_ok(h, (int)M) && prefill16_ok(h, M, cache_attn, logits_out);
+    const bool kv_only_last = !logits_out && !post && !tune(TUNE_DECODER_PREFILL_FULL);   // logits dropped: the last block stops at its K | V
     if (p16) {
-        MGEA_TRY(run_prefill16(h, ids, lens, B, T, logits_out, st));   // computes the logits itself (fp32 output of its head GEMM)
+        MGEA_TRY(run_prefill16(h, ids, lens, B, T, logits_out, st, kv_only_last));   // computes the logits itself (fp32 output of its head GEMM)
     } else if (fused_ok(h, (int)M)) {
         MGEA_TRY(launch_embed_stats(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->stats, B, T, C, V,
                                     c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
-        MGEA_TRY(run_blocks_fused(h, main_bufs(h), B, T, lens, cache_attn, st));
+        MGEA_TRY(run_blocks_fused(h, main_bufs(h), B, T, lens, cache_attn, st, kv_only_last));
     } else {
         MGEA_TRY(launch_embed_ln(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), h->x, h->xn,
                                  post ? nullptr : h->lw(0, L_LN1W), post ? nullptr : h->lw(0, L_LN1B), c.ln_eps, B, T, C,
                                  V, c.seq_len, (!post) && c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
-        MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st));
+        MGEA_TRY(run_blocks(h, B, T, lens, cache_attn, !post, st, kv_only_last));
     }
     if (p16) {
     } else if (logits_out && fused_ok(h, (int)M)) {

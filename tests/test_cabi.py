@@ -106,7 +106,7 @@ def test_switch_table_is_host_side_and_restorable():
         _lib.tune_set("bf16_gemm_tail", old)
     assert _lib.tune_get("bf16_gemm_tail") == old
     assert lib.mgea_tune_set(b"no_such_switch", 1) == _lib.EINVAL and "no_such_switch" in _lib.last_error()
-    for name in ("bf16_gemm_tile", "bf16_gemm_small", "bf16_gemm_phases", "bert_bf16_nofold", "bert_full_last_layer", "decoder_unfused", "decoder_nogemv", "decoder_nograph",
+    for name in ("bf16_gemm_tile", "bf16_gemm_small", "bf16_gemm_phases", "bert_bf16_nofold", "bert_full_last_layer", "decoder_prefill_full", "decoder_unfused", "decoder_nogemv", "decoder_nograph",
                  "decoder_prefill16"):
         assert lib.mgea_tune_get(name.encode(), C.byref(v)) == 0
 

@@ -447,3 +447,25 @@ def test_head_dim_96_reference_hard_coded_eight_heads():
     assert float((logits - want_l).abs().max()) < 1e-4
     for rows in ([0, 1, 2], [1]):
         check_greedy_vs_oracle(eng, ref, [prompts[i] for i in rows], 70, f"head_dim 96, rows {rows} x 70 steps")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "slab"])
+def test_prefill_whose_logits_are_dropped_stops_at_the_last_blocks_kv(golden, path, tune):
+    """sample_kvcache drops the logits of its prompt prefill (api_cache.py:163, `_, past = model(idx)`): nothing reads the last block's
+    output, so the engine's forward without a logits buffer ends once that block's K | V are in the cache (csrc/decoder.hip:
+    kv_only_last).  Same generation as with the whole last block computed (switch decoder_prefill_full = 1), on the fused path and on
+    the slab path; the golden id tests above run the short form by default."""
+    g = golden("decoder_tiny8h")
+    outs = {}
+    for full in (0, 1):
+        tune("decoder_prefill_full", full)
+        if path == "slab":
+            tune("decoder_unfused", 1)
+        eng, _, _ = make(g)
+        prompts = prompts_of(g)
+        outs[full] = eng.generate(prompts, 12, temperature=1.0, top_k=1).cpu()
+        eng.close()
+    assert torch.equal(outs[0], outs[1])
+    n = len(prompts[0])
+    assert prompts[0] + outs[0][0].tolist() == g["greedy0"].tolist()[:n + 12]

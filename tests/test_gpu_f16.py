@@ -204,6 +204,25 @@ def _p16_model():
     return sd, 4
 
 
+def test_f16_matrix_core_prefill_without_logits_stops_at_the_last_blocks_kv(tune):
+    """The prompt prefill of generate() drops its logits (api_cache.py:163): on the matrix-core path the last block then runs its
+    K | V projection (rows C.. of the stacked, LayerNorm-folded matrix) and the KV scatter only.  Same ids as with the whole last
+    block computed (switch decoder_prefill_full = 1)."""
+    from mgea.decoder import DecoderEngine
+    sd, n_head = _p16_model()
+    tune("decoder_prefill16", 2)
+    B, T = 8, 256
+    idx = torch.from_numpy(synth.integers(5, "p16", (B, T), 0, 300)).to(torch.int32)
+    outs = {}
+    for full in (0, 1):
+        tune("decoder_prefill_full", full)
+        eng = DecoderEngine(sd, n_head=n_head, max_batch=B, max_ctx=T + 8, dtype="f16")
+        outs[full] = eng.generate(idx, 7, temperature=1.0, top_k=1).cpu()
+        assert eng.stats()["prefill16_forwards"] == 1
+        eng.close()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_f16_matrix_core_prefill_vs_oracle_on_rounded_weights(ragged, tune):
     """api_cache.py:87-106 (prefill: every token attends to every token, no mask) in the fp16 perf mode's matrix-core form, forced
