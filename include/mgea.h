@@ -115,7 +115,8 @@ int mgea_decoder_reset(mgea_decoder* h, int32_t batch, int32_t max_len, void* st
  * NL blocks with every new token attending to the whole cache, no mask.  ids_dev [B,T] int32;
  * lens_dev [B] int32 or NULL (ragged rows: only the first lens[b] tokens of row b are real; the
  * rest are ignored and never cached, so each row equals its solo run).  logits_out_dev [B,T,V]
- * fp32 or NULL (the sampler's prefill discards them, api_cache.py:163). */
+ * fp32 or NULL (the sampler's prefill discards them, api_cache.py:163): without a logits buffer nothing reads the last block's
+ * output, and the call ends once that block's K | V are in the cache (switch decoder_prefill_full = 1 runs the whole block). */
 int mgea_decoder_forward(mgea_decoder* h, const int32_t* ids_dev, const int32_t* lens_dev,
                          int32_t B, int32_t T, float* logits_out_dev, void* stream);
 
@@ -181,7 +182,9 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_bert** out);
 int mgea_bert_destroy(mgea_bert* h);
 /* ids_dev [B,S] int32, mask_dev [B,S] int32 0/1 or NULL -> logits_out_dev [B,labels] fp32 and/or
- * argmax_out_dev [B] int32 (either may be NULL). */
+ * argmax_out_dev [B] int32 (either may be NULL).  The classifier reads hidden_state[:, 0] of the last layer only: for S >= 4 that layer
+ * projects K | V for every position and runs its query, attention, out-projection and FFN for the B [CLS] rows (same logits; switch
+ * bert_full_last_layer = 1 computes every position). */
 int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
                       int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
 /* What the handle ran (so that a test can assert WHICH kernels produced the numbers it checks): out[0] forwards so far; of the
