@@ -27,7 +27,8 @@ for s in $STEPS; do
     bench)     run bench 400 python3 bench.py --steps 2 --warmup 1 --no-cpu || exit 1 ;;
     benchfull) run benchfull 600 python3 bench.py || exit 1 ;;
     bertprof)  rm -rf /tmp/bp_$TAG; run bertprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp_$TAG -- python3 tools/bert_prof.py bf16 || exit 1
-               f=$(find /tmp/bp_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bert_bf16_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
+               f=$(find /tmp/bp_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bert_bf16_kernel_stats.csv && python3 tools/kstats.py $f "" 14
+               t=$(find /tmp/bp_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python3 tools/bert_layer_times.py $t > $OUT/bert_layer_times.txt ;;
     benchprof) rm -rf /tmp/bn_$TAG; run benchprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bn_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra || exit 1
                f=$(find /tmp/bn_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
     bertab)    run bertab 300 python3 tools/bert_ab.py bf16_gemm_tail 0 1 2 || exit 1 ;;
