@@ -453,7 +453,20 @@ def main():
                         traffic_source = (f"committed PMC constant profiles/{name} @ {rec.get('_commit', 'unknown')}: {rec.get('_command', 'rocprofv3 --pmc FETCH_SIZE')}, "
                                           f"mean of {v.get('n', v.get('dispatches', 'unknown'))} launches")
                 break
-            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+            # cross-check from the committed rocprofv3 --kernel-trace --stats pass of this command (profiles/): the kernel's own average
+            # duration, without the ~2.5 us of dispatch that an event pair around a single launch includes (all 1019 x 6 launches of a
+            # generation there, every 16th step here: the same mean context)
+            trace = None
+            kst = os.path.join(ROOT, "profiles", "r3_bench_kernel_stats.csv")
+            if os.path.exists(kst):
+                import csv
+                for r in csv.DictReader(open(kst)):
+                    if "attn_paged_kernel<64, false>" in r["Name"]:
+                        t_us = float(r["AverageNs"]) / 1e3
+                        alg = B * N_HEAD * 2 * (Tp + (n_steps - 1) / 2 + 1) * dh * 4     # mean over all steps of the generation
+                        trace = dict(avg_launch_us=t_us, launches=int(r["Calls"]), achieved=alg / (t_us * 1e-6) / 1e9,
+                                     frac=alg / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, source="profiles/r3_bench_kernel_stats.csv (committed pass, not this run)")
+            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, kernel_trace=trace,
                         traffic=traffic, traffic_source=traffic_source, kernel="attn_paged_kernel<64>", launches=a["launches"],
                         avg_launch_us=a["ms"] * 1e3 / a["launches"],
                         algorithmic_bytes_per_launch=bytes_total / a["launches"],
