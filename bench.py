@@ -172,6 +172,20 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None, r
         dtc = time.perf_counter() - t0
         out["cpu_baseline"] = dict(value=n / dtc, unit="prompts/s", cores=torch.get_num_threads(), kind="port",
                                    sample=f"oracle/distilbert_ref.py, first {n} rows of the batch, one forward, {dtc:.1f} s")
+    # the reference's own serving case for this model: ONE text per request (api_cache.py:189 -> inference.predict, B = 1), here a
+    # 32-token prompt through the same engine (forward + device argmax, ids already on the device)
+    i1, m1 = ids[:1, :32].contiguous(), torch.ones(1, 32, dtype=mask.dtype, device=device)
+    for _ in range(5):
+        eng.forward(i1, m1)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        eng.forward(i1, m1)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    out["single_prompt"] = dict(batch=1, tokens=32, ms_per_request=sorted(ts)[len(ts) // 2] * 1e3,
+                                note="one 32-token prompt per request, median of 30 (api_cache.py:189: the endpoint classifies one text)")
     if check is not None:
         out["parity_check"] = check
     if keep_logits:
