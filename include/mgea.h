@@ -36,7 +36,8 @@ extern "C" {
  *   decoder (mgea_decoder_config.dtype): F32, F16        DistilBERT (mgea_bert_config.dtype): F32, BF16
  * F32 is the parity mode of both (bit-exact greedy ids / labels against the reference's fp32 CPU path). */
 #define MGEA_DTYPE_F32   0   /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
-#define MGEA_DTYPE_BF16  1   /* DistilBERT perf mode: bf16 weights + activations, fp32 accumulate (bf16 MFMA) */
+#define MGEA_DTYPE_BF16  1   /* DistilBERT perf mode: bf16 weights + activations, fp32 accumulate (bf16 MFMA); calls of fewer than 512
+                                tokens (one text per request) run on the exact-fp32 kernels of the same engine */
 #define MGEA_DTYPE_F16   2   /* decoder perf mode: fp16 projection matrices + fp16 KV pages, fp32 accumulate (f16 MFMA),
                                 fp32 residual stream / LayerNorm / softmax / logits */
 

@@ -39,6 +39,8 @@ int bert_layout(const mgea_bert_config& c, std::vector<int64_t>* offs, int64_t* 
     return (int)sizes.size();
 }
 
+constexpr int64_t BF16_MIN_TOKENS = 512;   // bf16 engines: calls with fewer tokens run on the exact-fp32 kernels
+
 int validate(const mgea_bert_config* c) {
     MGEA_REQUIRE(c, MGEA_EINVAL, "bert config is NULL");
     MGEA_REQUIRE(c->vocab > 0 && c->max_pos > 0 && c->dim > 0 && c->n_heads > 0 && c->n_layers > 0 && c->hidden > 0 &&
@@ -135,11 +137,18 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
         // (M = batch rows) stays on the fp32 kernels
         const int64_t small = 32 * 64 * slab_ld((int)D), big = M * slab_ld((int)D);  // split-K (B <= 64) / one slab
         h->slab_cap = small > big ? small : big;
+        const int64_t f32_small = 2 * (M < BF16_MIN_TOKENS ? M : BF16_MIN_TOKENS) * slab_ld((int)nmax);   // the exact-fp32 path of small calls (room for a split of K)
+        if (f32_small > h->slab_cap) h->slab_cap = f32_small;
         ok = hipMalloc(&h->wb, total * 2) == hipSuccess && hipMalloc(&h->hb, M * D * 2) == hipSuccess &&
              hipMalloc(&h->qkvb, M * 3 * D * 2) == hipSuccess && hipMalloc(&h->ctxb, M * D * 2) == hipSuccess &&
              hipMalloc(&h->ffnb, M * Hd * 2) == hipSuccess && hipMalloc(&h->tmpb, M * D * 2) == hipSuccess &&
              hipMalloc((void**)&h->slabs, h->slab_cap * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
              hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
+        // small calls (fewer than BF16_MIN_TOKENS tokens: the endpoint's one text per request) run on the exact-fp32 kernels -- the 16-bit
+        // GEMMs need hundreds of rows to fill their tiles -- with fp32 activation buffers of that size
+        const int64_t Ms = M < BF16_MIN_TOKENS ? M : BF16_MIN_TOKENS;
+        if (ok) ok = hipMalloc((void**)&h->h, Ms * D * 4) == hipSuccess && hipMalloc((void**)&h->qkv, Ms * 3 * D * 4) == hipSuccess &&
+                     hipMalloc((void**)&h->ctx, Ms * D * 4) == hipSuccess && hipMalloc((void**)&h->ffn, Ms * Hd * 4) == hipSuccess;
         if (ok) ok = launch_f32_to_bf16(arena_dev, h->wb, total, nullptr) == MGEA_OK && hipDeviceSynchronize() == hipSuccess;
         if (ok) {   // folded-LayerNorm pipeline (see mgea_bert_forward): FC1 of every layer, QKV of layers >= 1
             const int64_t L = cfg->n_layers;
@@ -204,11 +213,13 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     // the inputs as computing every position and discarding all but one -- 1 / n_layers of the forward less about 2 / 3 of a QKV GEMM
     // (switch bert_full_last_layer = 1 computes every position; both are tested against the goldens).  The [B, 2 D + hidden] fp32
     // scratch is the FFN buffer, idle in that layer.
-    const int64_t cls_cap = c.dtype == MGEA_DTYPE_BF16 ? (int64_t)c.max_tokens * Hd / 2 : (int64_t)c.max_tokens * Hd;   // floats in ffnb / ffn
+    const bool use16_ = c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS;
+    const int64_t f32_rows = c.dtype == MGEA_DTYPE_BF16 ? (c.max_tokens < BF16_MIN_TOKENS ? c.max_tokens : BF16_MIN_TOKENS) : c.max_tokens;
+    const int64_t cls_cap = use16_ ? (int64_t)c.max_tokens * Hd / 2 : f32_rows * Hd;   // floats in ffnb / ffn
     bool cls_last = !tune(TUNE_BERT_FULL_LAST_LAYER) && S >= 4 && (int64_t)B * (2 * D + Hd) <= cls_cap;
     const int last = c.n_layers - 1;
     auto cls_tail = [&](int l, const void* kv, int kv_bf16) -> int {   // pooled [B, D] = the layer's input rows at [CLS]; kv = qkv buffer with K | V filled
-        float* cls = reinterpret_cast<float*>(c.dtype == MGEA_DTYPE_BF16 ? h->ffnb : (void*)h->ffn);
+        float* cls = reinterpret_cast<float*>(use16_ ? h->ffnb : (void*)h->ffn);
         float *cq = cls, *cctx = cls + (int64_t)B * D, *chid = cls + (int64_t)2 * B * D;
         MGEA_TRY(gemm(h->pooled, D, h->lw(l, BL_QKVW), B, D, D, &Sk));                     // q = x W_q^T + b_q (rows 0..D-1 of the stacked matrix)
         MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_QKVB), cq, D, B, D, ACT_NONE, st));
@@ -224,7 +235,12 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         return MGEA_OK;
     };
     h->last_cls_only = 0;
-    if (c.dtype == MGEA_DTYPE_BF16) {
+    const bool use16 = c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS;   // (bf16 engines: small calls take the exact-fp32 kernels below)
+    if (c.dtype == MGEA_DTYPE_BF16 && !use16) {
+        h->last_fold = h->last_persistent = h->last_ring = h->last_small = h->last_half_tiles = h->last_ln_kernels = 0;
+        for (int64_t& e : h->last_epi) e = 0;
+    }
+    if (use16) {
         // perf mode: bf16 MFMA GEMMs with fused bias / GELU / residual epilogues, bf16 flash attention
         auto wb = [&](int l, int j) { return (const void*)h->wbf(h->off[B_HEAD0 + l * BL_COUNT + j]); };
         h->last_fold = h->last_persistent = h->last_ring = h->last_small = h->last_half_tiles = h->last_ln_kernels = 0;
