@@ -1138,7 +1138,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                     const int id = tid + i * 512, pr = id >> 6, ch = id & 63;
                     const int row = cm0 + (pr >> 4) * wrows + k * 16 + (pr & 15), col = cn0 + ch * 4;
                     const float4 v = *reinterpret_cast<const float4*>(sC + pr * 1024 + ((ch ^ (pr & 15)) * 16));
-                    if (row < M && col < N) *reinterpret_cast<float4*>(Cf + (int64_t)row * ldc + col) = v;
+                    // 2.2 GB of logits at the decoder's [64, 1024] prefill that no kernel of the forward reads back: non-temporal stores
+                    if (row < M && col < N) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&v), reinterpret_cast<f32x4*>(Cf + (int64_t)row * ldc + col));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                     // the C stage is rewritten by the next pass
