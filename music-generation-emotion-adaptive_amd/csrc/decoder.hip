@@ -787,6 +787,10 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     } else if (logits_out) {
         for (int64_t r0 = 0; r0 < M; r0 += 4096) {
             const int rows = (int)((M - r0) < 4096 ? (M - r0) : 4096);
+            if (V % 4 == 0 && gemm_direct_epilogue_ok(rows, V)) {   // bias inside the GEMM: no slab write + read of rows x V floats (same sums: one slab)
+                PROF(PC_GEMM, launch_gemm_f32_bias_act(h->x + r0 * C, C, h->head_w(), C, h->head_b(), logits_out + r0 * V, V, rows, V, C, ACT_NONE, st));
+                continue;
+            }
             int S = 1;
             MGEA_TRY(gemm(h, h->x + r0 * C, C, h->head_w(), rows, V, C, &S, st));
             MGEA_TRY(launch_bias_act(h->slabs, S, slab_floats(rows, V), (int)slab_ld(V), h->head_b(),
