@@ -276,6 +276,15 @@ __global__ __launch_bounds__(256) void qkv_scatter_kernel(const float* __restric
     const bool cache_ok = real && page < max_pages;
     const int phys = cache_ok ? page_table[b * max_pages + page] : 0;
     const int nf4 = (3 * C) >> 2;
+    if (!qkv_out) {   // scatter only: P is the finished qkv buffer (bias applied by the GEMM's own epilogue), K | V of the real tokens -> pages
+        if (!cache_ok) return;
+        for (int f = (C >> 2) + threadIdx.x; f < nf4; f += 256) {
+            const int n = f * 4;
+            const int isv = n >= 2 * C, nn = n - (isv ? 2 * C : C);
+            kv_store4(pool, layer, phys, isv, nn / pool.dh, slot, nn % pool.dh, ld4(P + m * ldp + n));
+        }
+        return;
+    }
     for (int f = threadIdx.x; f < nf4; f += 256) {
         const int n = f * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
