@@ -121,11 +121,11 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None, r
         lg, am = eng.forward(ids, mask)
         d = (lg - ref_logits).abs().max(1).values
         srt = ref_logits.sort(1).values
-        decided = (srt[:, -1] - srt[:, -2]) > 0.16
+        decided = (srt[:, -1] - srt[:, -2]) > 0.10
         agree = bool((am[decided].long() == ref_logits.argmax(1)[decided]).all())
-        check = dict(vs="f32 engine, same ids, 256 rows", max_abs_logit_diff=float(d.max()), mean_row_max=float(d.mean()), tolerance=0.08,
-                     rows_with_top2_gap_over_0p16=int(decided.sum()), labels_equal_on_those=agree, kernels=eng.stats())
-        assert float(d.max()) < 0.08 and agree, f"bf16 DistilBERT logits off the f32 engine: {check}"
+        check = dict(vs="f32 engine, same ids, 256 rows", max_abs_logit_diff=float(d.max()), mean_row_max=float(d.mean()), tolerance=0.05,
+                     rows_with_top2_gap_over_0p10=int(decided.sum()), labels_equal_on_those=agree, kernels=eng.stats())
+        assert float(d.max()) < 0.05 and agree, f"bf16 DistilBERT logits off the f32 engine: {check}"
     from mgea import _lib
 
     def timed(full_last):

@@ -472,13 +472,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
     // reach their store bursts half a tile apart.
     const int full_rounds = per_x > 0 ? per_x / wg_x : 0, rem = per_x > 0 ? per_x - full_rounds * wg_x : 0;
     const bool split = (tail_mode & 3) != 0 && rem > 0 && 2 * rem <= wg_x;
-    const bool half_first = split && (tail_mode & 3) == 2 && (slot & 1) && slot < 2 * rem;
     int u_tile = 0, u_mode = 0;                              // mode 0: whole tile, 1 / 2: rows 0..127 / 128..255 of a shared tile
     // (tail_mode bit 2 = walk the XCD's run of tiles from its END: a GEMM whose A operand is the previous kernel's output and larger
     // than what the 256 MB Infinity Cache keeps of it -- DistilBERT's FC2 reads FC1's 201 MB -- otherwise reads that operand in the
     // order it was written, the one order in which an LRU cache that has just lost the head of the stream misses on every line)
     const bool rev = (tail_mode & 4) != 0;
     auto run_tile = [&](int idx) { return run0 + (rev ? per_x - 1 - idx : idx); };
+    // A lower half (mode 2: rows 128..255 of its tile) that starts at or beyond row M does not exist: with M % 256 in (0, 128] the
+    // last row tile has no second half, and its set_tile() clamp `M - 1 - lm0` would be negative -- as an unsigned LDS-DMA offset
+    // 4 GB past the end of A (found by reading; e.g. DistilBERT at B = 255, S = 128).  Such a workgroup has no tail unit.
+    const bool my_half = split && slot < 2 * rem &&
+                         !((slot & 1) && (run_tile(full_rounds * wg_x + (slot >> 1)) / tiles_n) * BM + 128 >= M);
+    const bool half_first = my_half && (tail_mode & 3) == 2 && (slot & 1);
     auto get_unit = [&](int ui) -> bool {                   // the ui-th unit of this workgroup
         if (half_first) {                                    // the tail unit comes first, the whole tiles after it
             if (ui == 0) { u_tile = run_tile(full_rounds * wg_x + (slot >> 1)); u_mode = 1 + (slot & 1); return true; }
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
         if (ui < full_rounds) { u_tile = run_tile(slot + ui * wg_x); u_mode = 0; return true; }
         if (ui > full_rounds) return false;
         if (split) {
-            if (slot >= 2 * rem) return false;
+            if (!my_half) return false;
             u_tile = run_tile(full_rounds * wg_x + (slot >> 1));
             u_mode = 1 + (slot & 1);
             return true;

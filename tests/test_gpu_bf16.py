@@ -217,6 +217,36 @@ def test_gemm_bf16_stream_across_tiles_with_odd_k_tiles(M, N, K, epi, phases, tu
                 assert torch.equal(out, first)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(8576, 2304, 768, 3), (8576, 2304, 768, 0), (32640, 768, 768, 5), (32896, 768, 3072, 5), (8576, 768, 192, 2)])
+@pytest.mark.parametrize("phases", [2, 1])
+def test_gemm_bf16_half_tile_tail_whose_lower_half_starts_at_m(M, N, K, epi, phases, tune):
+    """M % 256 == 128 and the last row tile in the half-tile tail.  The lower half of such a tile (rows 128..255)
+    starts AT row M, so it does not exist; round 3's kernel still created that unit and clamped its LDS-DMA row offsets with
+    `M - 1 - lm0` = -1 -> an unsigned offset 4 GB past the end of A.  8576 x 2304 = 306 tiles: XCD 7's run is 33 tiles on 32
+    workgroups, its one tail tile is the last tile of the last row tile.  32640 x 768 is the DistilBERT out-projection at B = 255,
+    S = 128 (384 tiles; tiles 368..383 in XCD 7's tail include row tile 127), 32896 = 257 x 128.  Every element against fp32
+    math on the same inputs; the three tail schedules bitwise equal (the whole-tile form never had the problem); nothing is written
+    beyond row M (the output tensor is followed by a guard band that must stay untouched)."""
+    from mgea import ops
+    tune("bf16_gemm_tile", 4)
+    tune("bf16_gemm_phases", phases)
+    assert M % 256 == 128
+    a, w, b, (want, scale), kw = _gemm_case(M, N, K, epi, seed=61)
+    first = None
+    for tail in (0, 1, 2):
+        tune("bf16_gemm_tail", tail)
+        info = []
+        got = ops.gemm_bf16(a, w, b, info=info, **kw)
+        assert info[0] == 2 and info[1] == int(tail != 0)
+        out = got[0] if epi == 5 else got
+        if first is None:
+            first = out
+            assert float(((out.float() - want).abs() / scale).max()) < BF16_REL
+        else:
+            assert torch.equal(out, first), f"tail schedule {tail} differs from whole tiles"
+    torch.cuda.synchronize()
+
+
 def test_gemm_bf16_row_statistics_of_offset_rows():
     """Rows whose mean is far from zero against their spread (outlier hidden dimensions of trained checkpoints; synthetic weights
     never produce them): epilogue 5 leaves (sum, M2 about the TILE mean) per tile and ln_rowstat merges the tiles exactly, so the
@@ -448,7 +478,7 @@ def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden, fu
     assert st["gemm_half_tile_tails"] == 3 * nl                     # QKV (4.5 rounds), out-proj and FC2 (1.5 rounds); FC1 is 6 whole rounds
     assert torch.equal(logits, logits2)                             # deterministic: no atomics, no exchange
     logits, amax = logits.cpu().numpy(), amax.cpu().numpy()
-    TOL = 0.08
+    TOL = 0.05                                                     # observed 0.024-0.027 on all 256 rows (rounds 3, 4)
     d = np.abs(logits - ref).max(1)
     print(f"[bf16 bench shape] max |logit - f32 engine| over 256 rows: {d.max():.4f} (mean {d.mean():.4f}); vs golden rows 0..7: "
           f"{np.abs(logits[:gb] - g['logits']).max():.4f}")
@@ -458,6 +488,32 @@ def test_bert_bf16_engine_at_the_bench_shape_vs_f32_engine_and_golden(golden, fu
     decided = (srt[:, -1] - srt[:, -2]) > 2 * TOL
     assert decided.sum() >= 16
     assert (amax[decided] == ref_amax[decided]).all()
+
+
+@pytest.mark.parametrize("B", [255, 257])
+def test_bert_bf16_engine_odd_batch_of_128_token_rows(B, tune):
+    """Plain engine input that reached ADVICE r3's out-of-bounds half unit: an odd batch at S = 128 (M = 128 B, M % 256 == 128) puts
+    the half-empty last row tile into the persistent GEMM's half-tile tail.  bf16 engine (its own dispatch, 2 layers of the base
+    geometry, every position of the last layer so that all GEMM shapes run on M rows) against the f32 engine on all rows."""
+    from mgea.bert import BertEngine
+    tune("bert_full_last_layer", 1)
+    S, L = 128, 2
+    sd = synth.distilbert_state_dict(9, 2000, 128, 768, L, 3072)
+    ids_np, mask_np = synth.bert_inputs(5, B, S, 2000)
+    ids, mask = torch.from_numpy(ids_np), torch.from_numpy(mask_np)
+    e32 = BertEngine(sd, n_heads=12, max_tokens=B * S, dtype="f32")
+    ref = e32.forward(ids, mask)[0].cpu().numpy()
+    e32.close()
+    eng = BertEngine(sd, n_heads=12, max_tokens=B * S, dtype="bf16")
+    logits, _ = eng.forward(ids, mask)
+    st = eng.stats()
+    logits2, _ = eng.forward(ids, mask)
+    eng.close()
+    assert st["gemm_persistent"] == 4 * L and st["gemm_half_tile_tails"] >= 2
+    assert torch.equal(logits, logits2)
+    d = np.abs(logits.cpu().numpy() - ref).max()
+    print(f"[bf16 odd batch {B} x 128] max |logit - f32 engine| = {d:.4f}")
+    assert d < 0.05
 
 
 def test_two_bf16_engines_on_two_streams_from_two_threads():

@@ -469,3 +469,64 @@ def test_prefill_whose_logits_are_dropped_stops_at_the_last_blocks_kv(golden, pa
     assert torch.equal(outs[0], outs[1])
     n = len(prompts[0])
     assert prompts[0] + outs[0][0].tolist() == g["greedy0"].tolist()[:n + 12]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["ragged_4x1000", "full_8x1024", "bench_64x1024"])
+def test_f32_long_prompt_prefill_and_decode_from_its_pages_vs_oracle(shape):
+    """GPTWithKV.forward returns logits for any T <= SEQ_LEN (api_cache.py:87-106), and `bench.py: extra.decoder_prefill` times the f32
+    engine on ids [64, 1024] -- the big-M path: gemm_f32_nt_kernel<128, 128> with bias / GELU in its epilogue, attn_dense over up to
+    1024 keys, the K | V scatter over 16 pages per row (csrc/decoder.hip: run_blocks).  VERDICT r3 #1: no f32 test prefilled more than
+    48 tokens.  Decoder-S geometry (6L / 512d / 8H, V = 8324, 1024 positions), the f32 engine's OWN dispatch:
+      * ragged prompts [4, 1000] with lengths 1000 / 517 / 64 / 1 (4000 rows; key masking by `lens`; page counts 16 / 9 / 1 / 1),
+        equal-length [8, 1024] (8192 rows, no mask, the position table used to its last row), or the benchmark's own [64, 1024]
+        (65536 rows x 8324 logits, the oracle needs ~30 s for it);
+      * logits of every REAL position against DecoderRef.forward: the north-star bar 1e-3 and what fp32 actually achieves;
+      * then 8 decode steps from the pages that prefill wrote: ids exact, step logits within 1e-3 (ragged case; the full case has no
+        room left in the 1024-token context for more than the bar's worth of steps, so it decodes 0 and the ragged case carries it)."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    torch.set_num_threads(16)
+    vocab, seq_len = 8324, 1024
+    sd = synth.decoder_state_dict(21, vocab, seq_len, 512, 6)
+    ref = DecoderRef(sd, 8)
+    if shape == "ragged_4x1000":
+        lens_l, T, n_dec = [1000, 517, 64, 1], 1000, 8
+    elif shape == "full_8x1024":
+        lens_l, T, n_dec = [1024] * 8, 1024, 0
+    else:                      # exactly what `extra.decoder_prefill` times: ids [64, 1024], logits of every position
+        lens_l, T, n_dec = [1024] * 64, 1024, 0
+    B = len(lens_l)
+    idx = torch.from_numpy(synth.integers(41, "long-" + shape, (B, T), 0, vocab)).long()
+    valid = torch.arange(T)[None, :] < torch.tensor(lens_l)[:, None]
+    idx = idx * valid            # padding ids are 0, as DecoderEngine.generate pads
+    ragged = not bool(valid.all())
+    lens = torch.tensor(lens_l, dtype=torch.int32) if ragged else None
+    eng = DecoderEngine(sd, n_head=8, max_batch=B, max_ctx=1024)
+    got = eng.reset_and_prefill(idx, lens, want_logits=True, max_len=min(1024, T + n_dec)).cpu()
+    want, cache, cvalid = ref.forward(idx, None, None, valid)
+    err = max(float((got[b][valid[b]] - want[b][valid[b]]).abs().max()) for b in range(B))
+    print(f"f32 long-prompt prefill {shape}: max |logit diff| vs oracle over {int(valid.sum())} positions x {vocab} = {err:.2e}")
+    assert err < LOGIT_TOL
+    assert err < 2e-4, f"f32 big-M prefill drifted: {err}"                     # what fp32 actually achieves (observed ~3e-5)
+    for b in range(B):         # argmax of every position the oracle decides by more than the observed error
+        top2 = want[b][valid[b]].topk(2, -1)
+        decided = (top2.values[:, 0] - top2.values[:, 1]) > 4 * err
+        assert bool((got[b][valid[b]].argmax(-1)[decided] == top2.indices[:, 0][decided]).all())
+    assert eng.context_lengths().cpu().tolist() == lens_l
+    if not n_dec:
+        return
+    # decode from the pages the big-M prefill wrote: the oracle continues from ITS cache (api_cache.py:166-168: the last real prompt
+    # token is fed again), the engine from the KV pages; ids must agree exactly, step logits within the bar
+    last = torch.tensor([int(idx[b, l - 1]) for b, l in enumerate(lens_l)]).view(B, 1)
+    samp = eng.sampler(1.0, 1)
+    worst = 0.0
+    for s in range(n_dec):
+        lg_ref, cache, cvalid = ref.forward(last, cache, cvalid, None)
+        out, lg = eng.step(None, samp, want_logits=True)
+        worst = max(worst, float((lg.cpu() - lg_ref[:, -1]).abs().max()))
+        last = lg_ref[:, -1].argmax(-1, keepdim=True)
+        assert out.cpu().tolist() == last.view(-1).tolist(), f"decode step {s} after the long prefill: ids differ from the oracle"
+    print(f"8 decode steps from those pages: ids exact, max |logit diff| = {worst:.2e}")
+    assert worst < LOGIT_TOL and worst < 2e-4
+    assert eng.context_lengths().cpu().tolist() == [l + n_dec for l in lens_l]

@@ -81,6 +81,26 @@ def test_attention_dense(ops, B, T, H, dh, masking):
     np.testing.assert_allclose(got[rows].numpy(), want[rows].numpy(), atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("B,T,H,dh", [(2, 1024, 8, 64), (1, 1000, 8, 64)])
+@pytest.mark.parametrize("masking", ["none", "lens"])
+def test_attention_dense_long_sequences(ops, B, T, H, dh, masking):
+    """The flash attention of the f32 prefill at the sequence lengths the [64, 1024] prefill benchmark runs it at (VERDICT r3 #1b: the
+    op test used to stop at T = 200): 16 key tiles per query block, masked (ragged `lens`: 1 key, a length that is no multiple of the
+    64-key tile, the whole sequence) and unmasked, every real query row against fp64 math (api_cache.py:68: MultiheadAttention, no mask)."""
+    C = H * dh
+    qkv = rnd(B, T, 3 * C, seed=17, scale=1.5)
+    valid = torch.ones(B, T, dtype=torch.bool)
+    lens = None
+    if masking == "lens":
+        lens = torch.tensor([[T, 517][b] if B == 2 else 1 for b in range(B)])
+        valid = torch.arange(T)[None, :] < lens[:, None]
+    got = ops.attention(qkv.cuda(), H, None if lens is None else lens.cuda(), None).cpu()
+    want = ref_attention(qkv, H, valid)
+    rows = valid
+    err = float((got[rows] - want[rows]).abs().max())
+    assert err < 2e-5, err
+
+
 def test_sampler_probabilities_match_reference_restatement(ops):
     from oracle.decoder_ref import DecoderRef
     logits = rnd(6, 8324, seed=11, scale=3.0)
