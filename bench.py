@@ -350,11 +350,17 @@ def dry_run(args, backend):
     per_rank = mdist.all_gather_floats(1000.0 + rank, "cpu")
     dt = mdist.all_reduce_max(1e-3 * (rank + 1), "cpu")
     assert ok and abs(dt - 1e-3 * world) < 1e-12 and per_rank == [1000.0 + r for r in range(world)]
+    # the prompt shards of the real run (BASELINE configs[3]: 64 prompts per GPU, 512 over 8): every rank reports the slice it would take
+    gb = 64 * world
+    mine = mdist.shard_rows(gb, rank, world)
+    firsts = [int(v) for v in mdist.all_gather_floats(float(mine.start), "cpu")]
+    counts = [int(v) for v in mdist.all_gather_floats(float(len(mine)), "cpu")]
+    assert counts == [64] * world and firsts == [64 * r for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "midi_tokens_per_sec", "value": 0.0, "unit": "tokens/s", "n_gpus": world, "steps": 0, "warmup": 0,
                           "dry_run": True, "backend": dist.get_backend() if world > 1 else None, "scaling": "weak",
-                          "per_rank_tokens_per_sec": per_rank,
-                          "config": {"workload": "launch-path rehearsal: no GPU work", "parallelism": parallelism_label(world, backend, n * 4, 0.0)}}))
+                          "per_rank_tokens_per_sec": per_rank, "rows_per_rank": counts, "first_row_per_rank": firsts,
+                          "config": {"workload": "launch-path rehearsal: no GPU work", "global_batch": gb, "parallelism": parallelism_label(world, backend, n * 4, 0.0)}}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -188,6 +188,11 @@ int mgea_bert_destroy(mgea_bert* h);
  * bert_full_last_layer = 1 computes every position). */
 int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
                       int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
+/* Token ids handed over as DEVICE memory are not read back before the forward (that would put a host sync in front of every call):
+ * an id outside [0, vocab) -- nn.Embedding raises IndexError in the reference (emotion_analysis/inference.py:16-17) -- is clamped by the
+ * embedding kernel and recorded in a sticky device flag.  This call synchronises `stream`, returns the flags (bit 0 = an id was clamped
+ * since the last call) in *flags_out (host) and clears them; same contract as mgea_decoder_error_flags. */
+int mgea_bert_error_flags(mgea_bert* h, int32_t* flags_out, void* stream);
 /* What the handle ran (so that a test can assert WHICH kernels produced the numbers it checks): out[0] forwards so far; of the
  * last forward: [1] 1 = folded-LayerNorm bf16 pipeline, [2] / [3] / [4] bf16 GEMM launches on the persistent 256 x 256 kernel /
  * a ring kernel / the 128 x 128 kernel, [5] persistent launches that cut their left-over tiles into 128-row halves,
@@ -270,6 +275,11 @@ int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const fl
                    const float* ln_c1_dev, const float* stats_in_dev, int32_t n_part,
                    int32_t part_cnt, float* out_dev, float* stats_out_dev, int32_t M, int32_t N, int32_t K,
                    int32_t act, int32_t dbg, void* stream);
+/* Number P of (max, argmax) partials per row that mgea_op_skinny(epi = 3) of this shape writes: stats_out_dev receives the maxima as
+ * float [row][P] (row stride P) followed, 64 * P floats in, by the int32 argmax indices in the same layout.  (The decode-step head of
+ * api_cache.py:105 runs as ONE balanced round of the chip where the shape allows -- csrc/head_gemm.hip, P = the CU count -- and on
+ * the generic skinny kernel otherwise; switch head_balanced.) */
+int mgea_op_skinny_logits_partials(int32_t M, int32_t N, int32_t K);
 /* Sampler on a logits matrix [B,V]; step selects the Philox counter.  probs_out_dev [B,V] or NULL
  * receives the pre-multinomial distribution. */
 int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s,

@@ -70,6 +70,7 @@ struct mgea_bert {
     // (persistent / ring / small), persistent launches that cut their tail tiles in halves, by epilogue (0..5); LayerNorm kernels
     int64_t n_forwards = 0, last_fold = 0, last_persistent = 0, last_ring = 0, last_small = 0, last_half_tiles = 0, last_ln_kernels = 0, last_cls_only = 0;
     int64_t last_epi[6] = {0, 0, 0, 0, 0, 0};
+    int32_t* err_flag = nullptr;   // sticky device flags (bit 0: a token id outside the vocabulary was clamped), as the decoder's
     // bf16 mode, folded-LayerNorm pipeline (big batches: every GEMM on the persistent kernel): W diag(gamma) copies, c1 / c2 vectors,
     // per-tile row sums and the two (mean, rstd) tables
     void* wfold = nullptr;
@@ -104,7 +105,7 @@ int mgea_bert_arena_layout(const mgea_bert_config* cfg, int64_t* offsets_floats,
 int mgea_bert_destroy(mgea_bert* h) {
     if (!h) return MGEA_OK;
     (void)hipDeviceSynchronize();
-    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->wfold, h->fvec, h->stats_part, h->rowstat_sa, h->rowstat_out, h->ident};
+    void* p[] = {h->h, h->qkv, h->ctx, h->ffn, h->slabs, h->pooled, h->pooled2, h->wb, h->hb, h->qkvb, h->ctxb, h->ffnb, h->tmpb, h->wfold, h->fvec, h->stats_part, h->rowstat_sa, h->rowstat_out, h->ident, h->err_flag};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;
@@ -178,6 +179,7 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
              hipMalloc((void**)&h->slabs, slab * 4) == hipSuccess && hipMalloc((void**)&h->pooled, M * D * 4) == hipSuccess &&
              hipMalloc((void**)&h->pooled2, M * D * 4) == hipSuccess;
     }
+    if (ok) ok = hipMalloc((void**)&h->err_flag, 16) == hipSuccess && hipMemset(h->err_flag, 0, 16) == hipSuccess;
     if (!ok) {
         set_error("bert_create: out of device memory");
         mgea_bert_destroy(h);
@@ -216,7 +218,10 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     const bool use16_ = c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS;
     const int64_t f32_rows = c.dtype == MGEA_DTYPE_BF16 ? (c.max_tokens < BF16_MIN_TOKENS ? c.max_tokens : BF16_MIN_TOKENS) : c.max_tokens;
     const int64_t cls_cap = use16_ ? (int64_t)c.max_tokens * Hd / 2 : f32_rows * Hd;   // floats in ffnb / ffn
-    bool cls_last = !tune(TUNE_BERT_FULL_LAST_LAYER) && S >= 4 && (int64_t)B * (2 * D + Hd) <= cls_cap;
+    // (cls_tail's fp32 GEMMs go through the slab workspace: [B, hidden] floats must fit too -- a geometry with hidden > S * dim did not,
+    // on a bf16 engine whose slab holds about M * dim floats, and got ECAPACITY where the every-position form ran: ADVICE r3)
+    bool cls_last = !tune(TUNE_BERT_FULL_LAST_LAYER) && S >= 4 && (int64_t)B * (2 * D + Hd) <= cls_cap &&
+                    slab_floats(B, D > Hd ? D : Hd) <= h->slab_cap;
     const int last = c.n_layers - 1;
     auto cls_tail = [&](int l, const void* kv, int kv_bf16) -> int {   // pooled [B, D] = the layer's input rows at [CLS]; kv = qkv buffer with K | V filled
         float* cls = reinterpret_cast<float*>(use16_ ? h->ffnb : (void*)h->ffn);
@@ -255,7 +260,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             return MGEA_OK;
         };
         MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
-                                           S, D, c.vocab, st));
+                                           S, D, c.vocab, st, h->err_flag));
         // Folded-LayerNorm pipeline: when every GEMM of a layer runs on the persistent 256 x 256 kernel (big batches), no LayerNorm
         // kernel runs at all.  The residual GEMMs write the RAW sums (x + sublayer(x)) and per-tile row sums; a 1-launch reduction
         // turns those into (mean, rstd) per row; the consumers apply the LayerNorm themselves: the next GEMM as rstd (A W'^T - mean
@@ -331,7 +336,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     } else {
     h->last_cls_only = cls_last ? 1 : 0;
     MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
-                                  D, c.vocab, st));
+                                  D, c.vocab, st, h->err_flag));
     for (int l = 0; l < c.n_layers; ++l) {
         if (cls_last && l == last) {               // K | V of every position (columns D.. of the stacked projection), the rest on the [CLS] rows
             const float *wkv = h->lw(l, BL_QKVW) + (int64_t)D * D, *bkv = h->lw(l, BL_QKVB) + D;
@@ -377,6 +382,18 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_TRY(launch_logits_argmax(h->slabs, Sk, slab_floats(B, NL), (int)slab_ld(NL), h->hw(3), logits_out_dev, B, NL,
                                   argmax_out_dev, st));
     h->n_forwards += 1;
+    return MGEA_OK;
+}
+
+int mgea_bert_error_flags(mgea_bert* h, int32_t* flags_out, void* stream) {
+    MGEA_REQUIRE(h && flags_out, MGEA_EINVAL, "bert_error_flags: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t v = 0;
+    MGEA_CHECK_HIP(hipMemcpyAsync(&v, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MGEA_CHECK_HIP(hipStreamSynchronize(st));
+    if (v) MGEA_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
+    *flags_out = v;
     return MGEA_OK;
 }
 

@@ -1622,12 +1622,14 @@ int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y
 __global__ __launch_bounds__(256) void bert_embed_ln_bf16_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
                                                                 const float* __restrict__ pos, const float* __restrict__ lnw,
                                                                 const float* __restrict__ lnb, float eps,
-                                                                bf16_t* __restrict__ h, int M, int S, int D, int vocab) {
+                                                                bf16_t* __restrict__ h, int M, int S, int D, int vocab,
+                                                                int32_t* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int t = (int)(row % S);
     int id = ids[row];
+    if ((id < 0 || id >= vocab) && err_flag && lane == 0) atomicOr(err_flag, 1);   // clamped + reported (mgea_bert_error_flags)
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const int nf4 = D >> 2;
     float4 v[8];
@@ -1661,10 +1663,10 @@ __global__ __launch_bounds__(256) void bert_embed_ln_bf16_kernel(const int32_t* 
     }
 }
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
-                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st) {
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag) {
     MGEA_REQUIRE(D % 4 == 0 && D <= 2048, MGEA_EINVAL, "bf16 embed: dim=%d must be a multiple of 4 and <= 2048", D);
     hipLaunchKernelGGL(bert_embed_ln_bf16_kernel, dim3(ceil_div(B * S, 4)), dim3(256), 0, st, ids, word, pos, lnw, lnb, eps,
-                       (bf16_t*)h, B * S, S, D, vocab);
+                       (bf16_t*)h, B * S, S, D, vocab, err_flag);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

@@ -38,6 +38,7 @@ const TuneEntry kTune[] = {
     {TUNE_ATTN16_WIDE, "attn16_wide", "MGEA_ATTN16_WIDE", 1},
     {TUNE_DECODER_PREFILL16_OVERLAP, "decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
     {TUNE_DECODER_PREFILL16, "decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
+    {TUNE_HEAD_BALANCED, "head_balanced", "MGEA_HEAD_BALANCED", 1},
 };
 static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];
@@ -219,12 +220,14 @@ int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const fl
     MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES || epi == EPI_LOGITS, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
     if (epi == EPI_LOGITS) {   // LM head: logits [M,N] row-major in out_dev (or NULL); per-tile (max, argmax) partials in stats_out_dev
         MGEA_REQUIRE(stats_out_dev, MGEA_EINVAL, "op_skinny: the LOGITS epilogue writes its partials to stats_out_dev");
-        const int tiles = skinny_logits_tiles(M, N);
+        const int tiles = skinny_logits_tiles(M, N, K);
         a.pmax_val = stats_out_dev;
         a.pmax_idx = reinterpret_cast<int32_t*>(stats_out_dev + (int64_t)64 * tiles);
     }
     return launch_skinny(epi, a, (hipStream_t)stream);
 }
+
+int mgea_op_skinny_logits_partials(int32_t M, int32_t N, int32_t K) { return skinny_logits_tiles(M, N, K); }
 
 int mgea_op_sample(const float* logits_dev, int32_t B, int32_t V, const mgea_sampler_config* s, int64_t step,
                    int32_t* ids_out_dev, float* probs_out_dev, void* stream) {

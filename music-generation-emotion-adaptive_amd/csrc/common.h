@@ -53,6 +53,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_DECODER_PREFILL16_OVERLAP,   // 1 (default): the KV scatter of the fp16 prefill runs on a side stream under the attention kernel
        TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
                                   // fills the chip (default), 2 whenever the kernels accept the shape (tests)
+       TUNE_HEAD_BALANCED,        // 1 (default): the LM head of a 3..64-row decode step on head_balanced_kernel (one workgroup per CU, equal unit counts); 0: the generic skinny kernel
        TUNE_COUNT };
 int tune(int key);
 
@@ -151,7 +152,7 @@ int launch_embed_ln(const int32_t* ids, const int32_t* lens, const int32_t* ctx_
 // BERT embedding: h[m] = LN(word[ids[m]] + pos[t])
 int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
                          const float* lnb, float eps, float* h, int B, int S, int D, int vocab,
-                         hipStream_t st);
+                         hipStream_t st, int32_t* err_flag = nullptr);
 // qkv epilogue of the decoder: v = sum P + bias over [M, 3C]; q -> qbuf[m, C] (and k|v -> kvbuf
 // [m, 2C] if kvbuf != NULL, for the no-cache attention); k, v of real tokens -> KV pages of `layer`
 // at position ctx_len[b] + t.
@@ -252,7 +253,7 @@ int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* 
                               hipStream_t st);
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
-                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st);
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag = nullptr);
 int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
 int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16 = 0);
 
@@ -296,7 +297,10 @@ int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st);
 // M <= 2 rows (single-stream decode): wave-level dot products on the ROW-MAJOR arena weights (gemv_small.hip)
 bool gemv_shape_ok(int M, int N, int K);
 int launch_gemv(int epi, const SkinnyArgs& a, hipStream_t st);
-int skinny_logits_tiles(int M, int N);
+int skinny_logits_tiles(int M, int N, int K);   // (max, argmax) partials per row that launch_skinny(EPI_LOGITS) of this shape writes
+// head_gemm.hip: the LM head of a decode step as one balanced round of the chip; launch returns 1 when the shape is not its own
+int head_balanced_partials(int M, int N, int K);
+int launch_head_balanced(const SkinnyArgs& a, hipStream_t st);
 int launch_embed_stats(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb,
                        const float* pos_emb, float* x, float* stats, int B, int T, int C, int vocab, int pos_rows,
                        int absolute_pos, int32_t* err_flag, hipStream_t st);

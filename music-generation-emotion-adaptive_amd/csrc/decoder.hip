@@ -468,18 +468,18 @@ int enqueue_step_fused(mgea_decoder* h, const Bufs& u, int B, const mgea_sampler
     a.M = B; a.A = u.x; a.lda = C; a.W = h->head_tw(); a.bias = h->head_b(); a.N = V; a.K = C;
     a.out = logits_out ? logits_out : (greedy ? nullptr : u.logits);
     a.ldo = V; a.pmax_val = u.pmax_val; a.pmax_idx = u.pmax_idx;
-    if (gemv_ok(h, B, 1, nullptr, true) && gemv_shape_ok(B, V, C)) {   // partial count = ceil(V / 16) = skinny_logits_tiles(B <= 32, V)
+    if (gemv_ok(h, B, 1, nullptr, true) && gemv_shape_ok(B, V, C)) {   // partial count = ceil(V / 16) = skinny_logits_tiles(B <= 2, V, C)
         a.W = h->head_w();
         PROF(PC_GEMM, launch_gemv(EPI_LOGITS, a, st));
     } else {
         PROF(PC_GEMM, launch_skinny(EPI_LOGITS, a, st));
     }
     if (greedy && primed) {
-        PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id, pd),
+        PROF(PC_SAMPLE, launch_argmax_advance_embed(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V, C), step_state(h, u, sc.eos_id, pd),
                                                     u.sampled, h->w(T_TOK), h->w(T_POS), u.x, u.stats, B, C, V, c.seq_len,
                                                     abs_pos, st));
     } else if (greedy) {
-        PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V), step_state(h, u, sc.eos_id, pd),
+        PROF(PC_SAMPLE, launch_argmax_advance(u.pmax_val, u.pmax_idx, skinny_logits_tiles(B, V, C), step_state(h, u, sc.eos_id, pd),
                                               u.sampled, B, st));
     } else {
         if (primed) {   // sampler + loop bookkeeping + next step's embedding in one launch
@@ -643,7 +643,9 @@ int ensure_p16(mgea_decoder* h, int64_t M, hipStream_t st) {
         p.rows = R;
     }
     if (!p.weights_ready) {
-        if (!p.w) {
+        if (!p.w || !p.vec) {
+            if (p.w) { (void)hipFree(p.w); p.w = nullptr; }
+            if (p.vec) { (void)hipFree(p.vec); p.vec = nullptr; }
             p.w_off.clear();
             int64_t tot = 0;
             for (int l = 0; l < NL; ++l) {
@@ -654,6 +656,10 @@ int ensure_p16(mgea_decoder* h, int64_t M, hipStream_t st) {
             }
             p.w_off.push_back(tot); tot += round_up(V, 256) * C;     // (rows beyond V are never read: the kernel clamps its row index)
             if (hipMalloc(&p.w, tot * 2) != hipSuccess || hipMalloc((void**)&p.vec, NL * (6 * C + 2 * F) * 4) != hipSuccess) {
+                // no half-built state: with p.w set and p.vec null the next prefill would skip this block and fold into a null table
+                if (p.w) (void)hipFree(p.w);
+                if (p.vec) (void)hipFree(p.vec);
+                p.w = nullptr; p.vec = nullptr; p.w_off.clear();
                 set_error("decoder: out of device memory for the fp16 prefill matrices");
                 return MGEA_ENOMEM;
             }
@@ -796,7 +802,9 @@ int do_forward(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int B, 
     } else if (logits_out) {
         for (int64_t r0 = 0; r0 < M; r0 += 4096) {
             const int rows = (int)((M - r0) < 4096 ? (M - r0) : 4096);
-            if (V % 4 == 0 && gemm_direct_epilogue_ok(rows, V)) {   // bias inside the GEMM: no slab write + read of rows x V floats (same sums: one slab)
+            if (V % 4 == 0 && gemm_direct_epilogue_ok(rows, V)) {   // bias inside the GEMM: no slab write + read of rows x V floats.  (Same sums as the slab form wherever that
+                                                                    // would not split K: from 256 tiles on.  A remainder chunk of 128..255 tiles used to run with K split; its
+                                                                    // logits differ from that form in the last bits of the fp32 sums, within the 5e-6 the long-prompt test observes.)
                 PROF(PC_GEMM, launch_gemm_f32_bias_act(h->x + r0 * C, C, h->head_w(), C, h->head_b(), logits_out + r0 * V, V, rows, V, C, ACT_NONE, st));
                 continue;
             }
@@ -911,6 +919,7 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
     h->force_unfused = tune(TUNE_DECODER_UNFUSED) == 1;   // A/B switches (tools/README.md), latched per engine
     h->no_gemv = tune(TUNE_DECODER_NOGEMV) == 1;
     h->no_graph = tune(TUNE_DECODER_NOGRAPH) == 1;
+    { DeviceInfo di; MGEA_TRY(device_info(&di)); }   // cached now: launchers ask for it inside graph capture
     h->pages_per_row_cap = ceil_div(cfg->max_ctx, MGEA_KV_PAGE_TOKENS);
     h->max_pages = h->pages_per_row_cap;
     h->kv.n_pages = cfg->max_batch * h->pages_per_row_cap;

@@ -429,6 +429,10 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
     MGEA_REQUIRE(a.M >= 1 && a.M <= MGEA_FUSED_MAX_ROWS, MGEA_EINVAL, "skinny gemm: M=%d not in 1..%d", a.M, MGEA_FUSED_MAX_ROWS);
     MGEA_REQUIRE(a.K % 32 == 0, MGEA_EINVAL, "skinny gemm: K=%d must be a multiple of 32", a.K);
     MGEA_REQUIRE(EPI == EPI_LOGITS || a.N % 16 == 0, MGEA_EINVAL, "skinny gemm: N=%d must be a multiple of 16", a.N);
+    if (EPI == EPI_LOGITS) {   // decode-step head: one balanced round of the chip where the shape allows (head_gemm.hip)
+        const int rc = launch_head_balanced(a, st);
+        if (rc != 1) return rc;
+    }
     if (EPI == EPI_LOGITS && !ln && a.M > 32 && a.N >= 4096 && !((a.dbg >> 8) & 0x1FF)) {
         // LM head: 32 rows x 32 columns per workgroup, W fetched from HBM once
         const int nw_head = pick_waves(a.K, false, 2);
@@ -454,7 +458,11 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
 }
 
 // number of per-row partial (max, argmax) entries the LOGITS epilogue writes = its grid.x
-int skinny_logits_tiles(int M, int N) { return (M > 32 && N >= 4096) ? ceil_div(N, 32) : ceil_div(N, 16); }
+int skinny_logits_tiles(int M, int N, int K) {
+    const int g = head_balanced_partials(M, N, K);
+    if (g) return g;
+    return (M > 32 && N >= 4096) ? ceil_div(N, 32) : ceil_div(N, 16);
+}
 
 int launch_skinny(int epi, const SkinnyArgs& a, hipStream_t st) {
     switch (epi) {

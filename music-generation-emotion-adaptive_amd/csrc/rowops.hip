@@ -145,12 +145,15 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __res
                                                            const float* __restrict__ word,
                                                            const float* __restrict__ pos, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, float eps,
-                                                           float* __restrict__ h, int S, int D, int vocab) {
+                                                           float* __restrict__ h, int S, int D, int vocab,
+                                                           int32_t* __restrict__ err_flag) {
     __shared__ float red[4];
     const int64_t m = blockIdx.x;
     const int t = (int)(m % S);
     const int nf4 = D >> 2;
     int id = ids[m];
+    // an id outside the vocabulary (nn.Embedding raises IndexError) is clamped and reported through the engine's sticky flag
+    if ((id < 0 || id >= vocab) && err_flag && threadIdx.x == 0) atomicOr(err_flag, 1);
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     RowRegs r;
 #pragma unroll
@@ -167,10 +170,10 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __res
 }
 
 int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
-                         const float* lnb, float eps, float* h, int B, int S, int D, int vocab, hipStream_t st) {
+                         const float* lnb, float eps, float* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag) {
     MGEA_REQUIRE(D % 4 == 0 && D <= 4096, MGEA_EINVAL, "bert embed: dim=%d must be a multiple of 4 and <= 4096", D);
     hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(B * S), dim3(256), 0, st, ids, word, pos, lnw, lnb, eps, h, S, D,
-                       vocab);
+                       vocab, err_flag);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

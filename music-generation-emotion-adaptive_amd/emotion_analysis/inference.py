@@ -52,7 +52,10 @@ def classify(text: Union[str, Sequence[str], torch.Tensor], attention_mask: Opti
         if model is None:
             configure()
         _, amax = model.forward(text, attention_mask, want_logits=False)
-        return [ID2LABEL[int(i)] for i in amax.cpu().tolist()]
+        labels = [ID2LABEL[int(i)] for i in amax.cpu().tolist()]
+        if text.is_cuda:
+            model.id_errors()     # device-resident ids were not read back before the forward: the IndexError of nn.Embedding comes here
+        return labels
     logits = _logits(list(text))
     return [ID2LABEL[int(i)] for i in logits.argmax(1).tolist()]
 

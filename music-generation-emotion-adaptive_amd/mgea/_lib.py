@@ -61,6 +61,7 @@ PROTOTYPES = {
     "mgea_decoder_context_lengths": (C.c_int, [_P, _P, _P]),
     "mgea_decoder_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "mgea_decoder_error_flags": (C.c_int, [_P, C.POINTER(_I32), _P]),
+    "mgea_bert_error_flags": (C.c_int, [_P, C.POINTER(_I32), _P]),
     "mgea_decoder_profile": (C.c_int, [_P, _I32]),
     "mgea_decoder_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "mgea_bert_arena_layout": (C.c_int, [C.POINTER(BertConfig), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "mgea_op_tile_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "mgea_op_fold_ln": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "mgea_op_skinny": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "mgea_op_skinny_logits_partials": (C.c_int, [_I32, _I32, _I32]),
     "mgea_op_sample": (C.c_int, [_P, _I32, _I32, C.POINTER(SamplerConfig), _I64, _P, _P, _P]),
 }
 

@@ -210,6 +210,16 @@ class BertEngine:
                     gemm_half_tile_tails=out[5], layernorm_kernels=out[6], last_layer_cls_only=bool(out[7]),
                     gemm_by_epilogue=[int(out[8 + e]) for e in range(6)])
 
+    def id_errors(self, raise_error: bool = True) -> int:
+        """Read and clear the engine's sticky device flags (ONE stream sync): bit 0 = some token id handed over as a DEVICE tensor
+        since the last call was outside the vocabulary (and was clamped); raises the IndexError nn.Embedding raises in the reference."""
+        flags = C.c_int32(0)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.mgea_bert_error_flags(self.h, C.byref(flags), st))
+        if raise_error and (flags.value & 1):
+            raise IndexError("index out of range in self")
+        return flags.value
+
     def forward(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, want_logits=True, want_argmax=True):
         """ids [B,S] (any int dtype), mask [B,S] 0/1 -> (logits [B,labels] fp32, argmax [B] int32)."""
         if ids.dim() != 2:
@@ -218,7 +228,8 @@ class BertEngine:
         # ids outside the vocabulary: nn.Embedding raises IndexError in the reference.  A HOST tensor (what the tokenizer hands over,
         # emotion_analysis/inference.py:14-16) is checked here at no GPU cost; a DEVICE tensor is not read back -- that put a host
         # sync and two reduction kernels in front of every forward (~0.1 ms of idle GPU per [256, 128] batch) -- the embedding
-        # kernel clamps such ids instead.
+        # kernel clamps such ids and sets a sticky device flag: id_errors() reads it (one sync, whenever the caller reads the logits
+        # anyway) and raises the reference's IndexError then.
         if not ids.is_cuda and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.geo["vocab"]):
             raise IndexError("index out of range in self")
         ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()

@@ -211,3 +211,22 @@ def skinny(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, residual: Op
     check(lib.mgea_op_skinny(2, ptr(at), ptr(wt), ptr(b), ptr(c1), ptr(st), n_part, 16, ptr(out), ptr(stats_out),
                              M, N, K, act, dbg, stream_ptr()))
     return untile_rows(out, M, N)
+
+
+def head(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, want_logits: bool = True):
+    """The LM head of a decode step (api_cache.py:105) on row-major inputs: returns (logits [M, N] or None, argmax [M] int64 merged from
+    the per-workgroup (max, argmax) partials the kernel leaves for the greedy tail, partial count P).  Which kernel runs -- the balanced
+    one-round kernel of csrc/head_gemm.hip or the generic skinny kernel -- follows the library's own routing (switch head_balanced)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    at, wt, b = tile_rows(a), tile_weights(w), _dev(bias.float())
+    P = int(lib.mgea_op_skinny_logits_partials(M, N, K))
+    part = torch.full((2 * 64 * P + 64,), float("nan"), dtype=torch.float32, device=a.device)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=a.device) if want_logits else None
+    check(lib.mgea_op_skinny(3, ptr(at), ptr(wt), ptr(b), None, None, 0, 16, ptr(out), ptr(part), M, N, K, 0, 0, stream_ptr()))
+    val = part[: 64 * P].view(64, P)[:M]
+    idx = part[64 * P: 2 * 64 * P].view(torch.int32).view(64, P)[:M].long()
+    best = val.max(1, keepdim=True).values
+    cand = torch.where(val == best, idx, torch.full_like(idx, 2 ** 31 - 1))
+    return out, cand.min(1).values, P

@@ -77,3 +77,30 @@ def test_last_layer_on_cls_rows_only_equals_every_position(dim, n_heads, S, tune
         eng.close()
     assert np.abs(out[0][0] - out[1][0]).max() < 2e-5
     assert (out[0][1] == out[1][1]).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_device_resident_ids_outside_the_vocabulary_are_reported(dtype, tune):
+    """nn.Embedding raises IndexError for an id outside the vocabulary (emotion_analysis/inference.py:16-17 -> transformers).  Host
+    tensors are checked before the upload; DEVICE tensors are not read back (no host sync in front of a forward): the embedding kernels
+    clamp such ids and set the engine's sticky flag, which id_errors() turns into the same IndexError (the check had been
+    dropped without a replacement).  Both embedding kernels: the fp32 one and, on a bf16 engine forced onto its 16-bit path, the bf16 one."""
+    from mgea.bert import BertEngine
+    sd = synth.distilbert_state_dict(5, 100, 32, 128, 2, 512)
+    eng = BertEngine(sd, n_heads=2, max_tokens=1024, dtype=dtype)
+    B, S = (8, 128) if dtype == "bf16" else (2, 8)       # bf16 engines take their 16-bit kernels from 512 tokens on
+    good = torch.randint(1, 100, (B, S), dtype=torch.int32)
+    with pytest.raises(IndexError):
+        eng.forward(torch.full((1, 4), 100))               # host tensor: refused before any GPU work
+    eng.forward(good.cuda())
+    assert eng.id_errors(raise_error=False) == 0
+    bad = good.clone()
+    bad[B - 1, 3] = 100
+    eng.forward(bad.cuda())                                # no exception yet: nothing was synchronised
+    with pytest.raises(IndexError):
+        eng.id_errors()
+    assert eng.id_errors(raise_error=False) == 0            # reading clears the flag
+    bad[0, 0] = -1
+    eng.forward(bad.cuda())
+    assert eng.id_errors(raise_error=False) == 1
+    eng.close()

@@ -246,3 +246,42 @@ def test_skinny_gemm_more_than_64_rows(ops, M, N, K):
         assert (stats.cpu() - tile_stats(ref.float())).abs().max().item() < 1e-4
     y = rnd(M, 768, seed=37).cuda()
     assert torch.equal(ops.untile_rows(ops.tile_rows(y), M, 768), y)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 8324, 512), (3, 8324, 512), (33, 8324, 768), (64, 5008, 256), (17, 12401, 512), (48, 4100, 512),
+                                   (64, 300, 512), (2, 8324, 512)])
+def test_lm_head_balanced_one_round_kernel_equals_the_generic_kernel_bitwise(ops, M, N, K, tune):
+    """csrc/head_gemm.hip (round 4): the decode-step head as ONE workgroup per CU with equal unit counts.  Same K split over the
+    8 waves, same MFMA chain per output element, same wave-order sum as gemm_skinny_kernel: logits BITWISE equal to the generic kernel's
+    (switch head_balanced = 0) for every shape the new kernel takes -- 1, 2 and 3 column tiles per workgroup (N = 5008 / 8324 / 12401),
+    K of 1, 2 and 3 chunks per wave, ragged row counts, N not a multiple of 16 or 4 -- and within fp32 summation noise of fp64;
+    the greedy (max, argmax) partials merge to torch.argmax with the LOWEST index on exact ties (two duplicated weight rows carry the
+    row maximum).  N = 300 and M = 2 are shapes it must decline (the generic kernel / the dot-product path run)."""
+    a = rnd(M, K, seed=71)
+    w = rnd(N, K, seed=72, scale=K ** -0.5)
+    b = rnd(N, seed=73)
+    hi = [5, N // 2 + 3, N - 1]
+    w[hi[1]] = w[hi[0]]; w[hi[2]] = w[hi[0]]
+    b[hi[1]] = b[hi[0]]; b[hi[2]] = b[hi[0]]
+    want = (a.double() @ w.double().t() + b.double())
+    outs = {}
+    for sw in (1, 0):
+        tune("head_balanced", sw)
+        lg, am, P = ops.head(a.cuda(), w.cuda(), b.cuda())
+        outs[sw] = (lg.cpu(), am.cpu(), P)
+    takes = 3 <= M <= 64 and K in (256, 512, 768) and N // 16 >= 256
+    assert (outs[1][2] != outs[0][2]) == takes, (outs[1][2], outs[0][2])
+    if takes:
+        assert outs[1][2] % 8 == 0 and outs[1][2] >= 8            # one partial per workgroup = per CU
+    assert torch.equal(outs[1][0], outs[0][0]), "balanced head kernel and generic kernel differ bitwise"
+    assert float((outs[1][0].double() - want).abs().max()) < 2e-5
+    for sw in (1, 0):
+        lg, am, _ = outs[sw]
+        assert am.tolist() == [int((lg[r] == lg[r].max()).nonzero()[0]) for r in range(M)]     # first index of the row maximum
+    # exact ties: make the three duplicated columns every row's maximum, the partial merge must return the first of them
+    b2 = b.clone()
+    b2[hi] += 100.0
+    for sw in (1, 0):
+        tune("head_balanced", sw)
+        lg, am, _ = ops.head(a.cuda(), w.cuda(), b2.cuda(), want_logits=(sw == 1))
+        assert am.cpu().tolist() == [hi[0]] * M
