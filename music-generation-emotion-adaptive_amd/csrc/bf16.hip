@@ -381,11 +381,13 @@ typedef unsigned long long u64x1;
 // MGEA_DTYPE_F16) behind one set of kernels: vector types, the 16 x 16 x 32 MFMA, and a packed pair (one dword) <-> two fp32.
 template <typename T> struct X16;
 template <> struct X16<__bf16> {
+    static constexpr bool is_bf16 = true;
     typedef bf16x8 v8; typedef bf16x4 v4; typedef bf16x2 v2;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x2 unpack(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 };
 template <> struct X16<_Float16> {
+    static constexpr bool is_bf16 = false;
     typedef h16x8 v8; typedef h16x4 v4; typedef _Float16 v2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x2 unpack(unsigned u) {
@@ -1687,11 +1689,15 @@ int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipSt
 // v_permlane32_swap / v_permlane16_swap: VALU instructions, no trip through the LDS pipeline like ds_bpermute (__shfl_xor), which
 // matters at 2 waves per SIMD where nothing hides that latency.  swap(x, x) leaves [lo, lo] / [hi, hi] (32) or [r0 r0 r2 r2] / [r1 r1
 // r3 r3] (16) in the two results, so one max of the pair is the xor-32 / xor-16 butterfly step.
+// max(a, b) as the median of (a, b, +inf): ONE v_med3_f32.  fmaxf() on values that come out of an MFMA or a lane swap costs two extra
+// instructions each -- hipcc canonicalises both inputs first (v_max_f32 x, x, x: IEEE maxNum semantics for signalling NaNs), 16 + 8 of them
+// per 64-key tile of the flash attention.  No score is a NaN here; -inf (masked keys) orders as usual.
+__device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
 __device__ __forceinline__ float quad_max(float x) {
     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const float m = max_nc(__uint_as_float(a[0]), __uint_as_float(a[1]));
     const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return max_nc(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1716,10 +1722,10 @@ __device__ __forceinline__ float quad_max(float x) {
 // of a (batch, head) leave HBM exactly once --, <8, 256> (one workgroup per CU, 2 x 64 KB stages) for long ones, where the per-unit costs (the
 // wait for the DMA, the barrier, 8 LDS-DMA pieces per wave: 1.7 of 4.3 us per unit by in-kernel stamps at 1024 keys) are spread over four
 // 64-key tiles instead of two.
-template <typename E, int NW>
+template <typename E, int NW, int PIPE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mask, E* __restrict__ out, int T, int H,
-                      int n_items, int nqb, float scale) {
+                      int n_items, int nqb, float scale, KvPages pg) {
     typedef typename X16<E>::v8 bf16x8;   // (the names below were written for bf16; E may be _Float16)
     typedef typename X16<E>::v4 bf16x4;
     typedef E bf16_t;
@@ -1742,11 +1748,13 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     const int d_key = lane >> 3, d_ch = lane & 7;                 // this lane's slot inside an 8-key piece
     const unsigned dk_off = 2u * C + 16u * (d_ch ^ d_key);                              // K: chunk ^ (key & 7), key & 7 == d_key
     const unsigned dv_off = 4u * C + 16u * (d_ch ^ (((d_key >> 1) & 3) << 1));          // V: chunk ^ 2 ((key >> 1) & 3)
-    auto issue = [&](int it, int kbi, int st) {
-        const int bh = it / nqb, bb = bh / H, hh = bh - bb * H;   // wave-uniform: the base stays in SGPRs
-        const bf16_t* base = qkv + (int64_t)bb * T * 3 * C + hh * DH;
+    auto item_base = [&](int it) {                                // first qkv row of the item's (batch, head): wave-uniform, stays in SGPRs
+        const int bh = it / nqb, bb = bh / H, hh = bh - bb * H;
+        return qkv + (int64_t)bb * T * 3 * C + hh * DH;
+    };
+    auto issue_part = [&](const bf16_t* base, int kbi, int st, int i0, int i1) {   // pieces i0 .. i1 - 1 of this wave's four (K and V of 8 keys each)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int piece = wave * 4 + i, key = piece * 8 + d_key;
             int kr = kbi * KB + key; kr = kr < T ? kr : T - 1;
             const unsigned row = (unsigned)kr * (unsigned)(6 * C);    // bytes; a sequence's rows span < 4 GB (checked on the host)
@@ -1755,6 +1763,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
             glds16_hidden_s(base, row + dv_off, dst + (unsigned)(KB * 8) * 16u);
         }
     };
+    auto issue = [&](int it, int kbi, int st) { issue_part(item_base(it), kbi, st, 0, 4); };
     auto mask_of = [&](int it, int kbi) -> int {                  // validity of key kbi * KB + tid (the first KB / 64 waves)
         const int bh = it / nqb, bb = bh / H;
         const int kidx = kbi * KB + tid;
@@ -1831,10 +1840,59 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 qf[mq][1] = qn[mq][1];
             }
         }
+        // K | V OF THE REAL TOKENS -> fp16 KV PAGES (decoder prefill, round 4; replaces kv_scatter_f16_kernel, which re-read the K | V columns
+        // of the qkv buffer from HBM -- 134 MB in, 134 MB out per layer at [64, 1024]).  The stage that has just landed holds exactly
+        // those rows: ONE of the (batch, head)'s items writes them out (below), each wave the 32 keys it moved in -- K as
+        // [d-group][token][8 halves] (lane = token: 512 contiguous bytes per d-group and instruction), V as whole 128-byte rows.
+        // Only keys with their validity bit set (t < lens[b], t < T) are cached, at position t (the cache is empty: run_prefill16).
+        if constexpr (sizeof(E) == 2 && !X16<E>::is_bf16) {
+            if (pg.pool.base) {
+                const int bh_u = item / nqb, qb_u = item - bh_u * nqb;
+                if (qb_u == kb) {     // (nqb == nkb: queries per item = keys per stage.  The item of query block kb writes key block kb -- every
+                                      //  workgroup a quarter of the stages; with query block 0 writing all of them a quarter of the workgroups
+                                      //  did all the writing and the launch waited for them: 4.64 ms per cache fill against 4.37 with the scatter kernel)
+                    const int bb = bh_u / H, hh = bh_u - bb * H;
+                    const int tok0 = kb * KB + wave * 32;                                   // 32-aligned: one page
+                    const unsigned long long vw = sValid[stage * VW + (wave >> 1)];
+                    const unsigned vbits = (unsigned)(vw >> (32 * (wave & 1)));             // validity of this wave's 32 keys
+                    if (tok0 < T && (tok0 >> 6) < pg.max_pages) {
+                        const int phys = pg.page_table[bb * pg.max_pages + (tok0 >> 6)];
+                        const int64_t pe = pg.pool.page_elems();
+                        _Float16* kpage = static_cast<_Float16*>(pg.pool.base) + pg.layer * pg.pool.layer_stride + ((int64_t)(phys * 2) * H + hh) * pe;
+                        _Float16* vpage = kpage + (int64_t)H * pe;
+                        const int slot0 = tok0 & 63;
+                        const float4* sKs = lds + stage * STAGE;
+                        const float4* sVs = sKs + KB * 8;
+                        {   // K: lane -> (token lane & 31, d-group 2 i + (lane >> 5))
+                            const int tk = lane & 31, key = wave * 32 + tk;
+                            const bool ok = (vbits >> tk) & 1u;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int j = 2 * i + (lane >> 5);
+                                const float4 v = sKs[key * 8 + (j ^ (key & 7))];
+                                if (ok) *reinterpret_cast<float4*>(kpage + ((int64_t)j * 64 + slot0 + tk) * 8) = v;
+                            }
+                        }
+                        {   // V: lane -> (token 8 i + (lane >> 3), 16-byte chunk lane & 7): 1 KB of consecutive bytes per instruction
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int tk = 8 * i + (lane >> 3), key = wave * 32 + tk, ch = lane & 7;
+                                const float4 v = sVs[key * 8 + (ch ^ (((key >> 1) & 3) << 1))];
+                                if ((vbits >> tk) & 1u) *reinterpret_cast<float4*>(vpage + ((int64_t)(slot0 + tk) * 64 + ch * 8)) = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
         int nitem = item, nkbi = kb + 1;
         if (nkbi == nkb) { nitem = item + gridDim.x; nkbi = 0; }
+        // PIPE, full stage: the next unit's 8 LDS-DMA pieces are issued inside the tile loop below, a quarter per tile, instead of as a
+        // burst here (stamps, round 3: 0.85 us per unit during which all 8 waves only issue and the matrix pipe idles)
+        const bool dma_in_loop = PIPE && NW == 8 && (kb + 1) * KB <= T;
+        const bf16_t* nbase = item_base(nitem < n_items ? nitem : item);   // (two integer divisions: once per unit, not once per piece)
         if (nitem < n_items) {                                    // the other stage was last read before the barrier above
-            issue(nitem, nkbi, stage ^ 1);
+            if (!dma_in_loop) issue(nitem, nkbi, stage ^ 1);
             mk = mask_of(nitem, nkbi);
             if (nkbi == 0) load_q(nitem);
         }
@@ -1844,16 +1902,9 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
 
         const float4* sK = lds + stage * STAGE;
         const bf16_t* sV = reinterpret_cast<const bf16_t*>(lds + stage * STAGE + KB * 8);
-#pragma unroll 1
-        for (int t0 = 0; t0 < KB && kb * KB + t0 < T; t0 += 64) {   // workgroup-uniform bounds
-            const unsigned long long vm = sValid[stage * VW + (t0 >> 6)];
-            const unsigned vm_lo = __builtin_amdgcn_readfirstlane((unsigned)vm), vm_hi = __builtin_amdgcn_readfirstlane((unsigned)(vm >> 32));
-            const bool all_valid = (vm_lo & vm_hi) == 0xffffffffu;                         // wave-uniform
-            const unsigned vb_lo = vm_lo >> (4 * g), vb_hi = vm_hi >> (4 * g);              // bit 16 (kt & 1) + r of word kt >> 1
-            bf16x8 pf[2][2];  // [query block][32-key half]
-            const bool first_tile = kb == 0 && t0 == 0;
-            // both query blocks side by side: two independent dependency chains per wave (there are only 2 waves per SIMD)
-            f32x4 sc[2][4];
+        // ---- one 64-key tile in three pieces (lambdas, so that the two loop forms below share them) ----
+        // S^T = K Q^T of keys t0 .. t0 + 63 against the wave's 32 queries: two independent chains per key tile (both query blocks)
+        auto qk_tile = [&](int t0, f32x4 (&sc)[2][4]) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) { sc[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
@@ -1866,6 +1917,13 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                     sc[0][kt] = X16<E>::mfma(kf, qf[0][ks], sc[0][kt]);
                     sc[1][kt] = X16<E>::mfma(kf, qf[1][ks], sc[1][kt]);
                 }
+        };
+        // key mask, tile maximum, and the (rare) move of the scaling reference with its accumulator rescale
+        auto tile_max = [&](int t0, f32x4 (&sc)[2][4], bool first_tile) {
+            const unsigned long long vm = sValid[stage * VW + (t0 >> 6)];
+            const unsigned vm_lo = __builtin_amdgcn_readfirstlane((unsigned)vm), vm_hi = __builtin_amdgcn_readfirstlane((unsigned)(vm >> 32));
+            const bool all_valid = (vm_lo & vm_hi) == 0xffffffffu;                         // wave-uniform
+            const unsigned vb_lo = vm_lo >> (4 * g), vb_hi = vm_hi >> (4 * g);              // bit 16 (kt & 1) + r of word kt >> 1
             float tmax[2];
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq) {
@@ -1877,7 +1935,8 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sc[mq][kt][r] = ((w >> (16 * (kt & 1) + r)) & 1u) ? sc[mq][kt][r] : -INFINITY;
                     }
-                    tmax[mq] = fmaxf(tmax[mq], fmaxf(fmaxf(sc[mq][kt][0], sc[mq][kt][1]), fmaxf(sc[mq][kt][2], sc[mq][kt][3])));
+                    const float m4 = max_nc(max_nc(sc[mq][kt][0], sc[mq][kt][1]), max_nc(sc[mq][kt][2], sc[mq][kt][3]));
+                    tmax[mq] = kt == 0 ? m4 : max_nc(tmax[mq], m4);
                 }
             }
             tmax[0] = quad_max(tmax[0]);
@@ -1892,9 +1951,9 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 const bool g0 = (tmax[0] - mx[0]) * kexp > RESCALE_LOG2, g1 = (tmax[1] - mx[1]) * kexp > RESCALE_LOG2;   // -inf - -inf = NaN: false
                 grow = __any((g0 || g1) ? 1 : 0) != 0;                                                                  // wave-uniform
             }
+            if (grow) {
 #pragma unroll
-            for (int mq = 0; mq < 2; ++mq) {
-                if (grow) {
+                for (int mq = 0; mq < 2; ++mq) {
                     const float mnew = fmaxf(mx[mq], tmax[mq]);
                     if (!first_tile) {
                         // alpha = 2^((m_old - m_new) kexp); rows that had no valid key so far carry zeros: any finite alpha will do
@@ -1907,30 +1966,68 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                     }
                     mx[mq] = mnew;
                 }
+            }
+        };
+        // P = 2^((s - m) kexp) as the 16-bit operand (straight from the accumulator registers), its row sums, and O += P V
+        auto exp_half = [&](f32x4 (&sc)[2][4], bf16x8 (&pf)[2][2], int p) {
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq) {
                 const float nml = (mx[mq] == -INFINITY) ? 0.f : -mx[mq] * kexp;   // a row without a valid key yet: p = 2^(-inf) = 0
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 2 * p; kt < 2 * p + 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        pf[mq][kt >> 1][(kt & 1) * 4 + r] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(sc[mq][kt][r], kexp, nml));
+                        pf[mq][p][(kt & 1) * 4 + r] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(sc[mq][kt][r], kexp, nml));
             }
+        };
+        auto pv_half = [&](int t0, bf16x8 (&pf)[2][2], int p) {
+            lacc[0] = X16<E>::mfma(ones, pf[0][p], lacc[0]);      // row sums of the 16-bit P the P V product actually uses
+            lacc[1] = X16<E>::mfma(ones, pf[1][p], lacc[1]);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {                         // row sums of the bf16 P the P V product actually uses
-                lacc[0] = X16<E>::mfma(ones, pf[0][p], lacc[0]);
-                lacc[1] = X16<E>::mfma(ones, pf[1][p], lacc[1]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* vb = sV + (t0 + 32 * p) * 64 + v_off[dt];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 16 * 64));
+                union { s16x4 s[2]; bf16x8 v; } u;
+                u.s[0] = lo; u.s[1] = hi;
+                oacc[0][dt] = X16<E>::mfma(u.v, pf[0][p], oacc[0][dt]);
+                oacc[1][dt] = X16<E>::mfma(u.v, pf[1][p], oacc[1][dt]);
             }
+        };
+        if (PIPE && (kb + 1) * KB <= T) {
+            // SOFTWARE-PIPELINED form for a full stage (round 4).  In the rolled loop below a tile is Q K^T (16 MFMAs), then ~190 vector
+            // instructions of softmax, then P V (20 MFMAs): matrix pipe and vector ALU take turns -- 576 + ~770 cycles per wave and
+            // tile, and the two waves of a SIMD, which run the same program between the same barriers, do it in lockstep (2,600 cycles
+            // per pair of tiles by in-kernel stamps, round 3: the SUM).  Here the stage's tiles are unrolled and the NEXT tile's
+            // Q K^T is issued between this tile's maximum and its exponentials (scores double-buffered, +32 registers), and P V of the
+            // first 32 keys runs under the exponentials of the other 32: the MFMAs of one tile sit in the shadow of the vector work of
+            // its neighbours, inside ONE wave's instruction stream (hipcc interleaves what is independent within a basic block).
+            constexpr int NT = KB / 64;
+            f32x4 sc[2][2][4];
+            qk_tile(0, sc[0]);
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16_t* vb = sV + (t0 + 32 * p) * 64 + v_off[dt];
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 16 * 64));
-                    union { s16x4 s[2]; bf16x8 v; } u;
-                    u.s[0] = lo; u.s[1] = hi;
-                    oacc[0][dt] = X16<E>::mfma(u.v, pf[0][p], oacc[0][dt]);
-                    oacc[1][dt] = X16<E>::mfma(u.v, pf[1][p], oacc[1][dt]);
-                }
+            for (int i = 0; i < NT; ++i) {
+                tile_max(64 * i, sc[i & 1], kb == 0 && i == 0);
+                if (dma_in_loop && nitem < n_items) issue_part(nbase, nkbi, stage ^ 1, i * 4 / NT, (i + 1) * 4 / NT);
+                bf16x8 pf[2][2];
+                if (i + 1 < NT) qk_tile(64 * (i + 1), sc[(i + 1) & 1]);
+                exp_half(sc[i & 1], pf, 0);
+                exp_half(sc[i & 1], pf, 1);
+                pv_half(64 * i, pf, 0);
+                pv_half(64 * i, pf, 1);
+            }
+        } else {
+#pragma unroll 1
+            for (int t0 = 0; t0 < KB && kb * KB + t0 < T; t0 += 64) {   // workgroup-uniform bounds
+                f32x4 sc[2][4];                                   // both query blocks side by side: two independent dependency chains per wave
+                bf16x8 pf[2][2];                                  // [query block][32-key half]
+                qk_tile(t0, sc);
+                tile_max(t0, sc, kb == 0 && t0 == 0);
+                exp_half(sc, pf, 0);
+                exp_half(sc, pf, 1);
+                pv_half(t0, pf, 0);
+                pv_half(t0, pf, 1);
+            }
         }
 
         PH_STAMP(un * 8 + 4);
@@ -1973,8 +2070,8 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
 #undef MGEA_FLUSH_OUT
 }
 
-template <typename E, int NW>
-static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, hipStream_t st) {
+template <typename E, int NW, int PIPE>
+static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, hipStream_t st, const KvPages& pg) {
     constexpr int QPB = 32 * NW, KB = 32 * NW;
     const int nqb = ceil_div(T, QPB);
     const int64_t n_items = (int64_t)B * H * nqb;
@@ -1983,24 +2080,35 @@ static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B,
     MGEA_TRY(device_info(&di));
     const int shmem = 2 * KB * 16 * 16 + 64;
     static uint64_t attr_done = 0;                     // per instantiation
-    MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<E, NW>, shmem, di.dev, &attr_done));
+    MGEA_TRY(set_max_dynamic_lds((const void*)attn_bf16_kernel<E, NW, PIPE>, shmem, di.dev, &attr_done));
     const int per_cu = NW == 4 ? 2 : 1;
     const int grid = (int)(n_items < per_cu * di.n_cu ? n_items : per_cu * di.n_cu);
-    hipLaunchKernelGGL((attn_bf16_kernel<E, NW>), dim3(grid), dim3(64 * NW), shmem, st, (const E*)qkv, mask, (E*)out, T, H, (int)n_items, nqb,
-                       0.125f);
+    hipLaunchKernelGGL((attn_bf16_kernel<E, NW, PIPE>), dim3(grid), dim3(64 * NW), shmem, st, (const E*)qkv, mask, (E*)out, T, H, (int)n_items, nqb,
+                       0.125f, pg);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
 
-int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16) {
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16, const KvPages* pages) {
     MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
     MGEA_REQUIRE((int64_t)T * 6 * H * dh < ((int64_t)1 << 32), MGEA_EINVAL, "bf16 attention: one sequence of qkv rows must span < 4 GB");
     // long sequences: 256 queries / 256 keys per unit (switch attn16_wide: 0 never, 1 from 512 tokens (default), 2 always)
     const int wide = tune(TUNE_ATTN16_WIDE);
     const bool w8 = wide == 2 || (wide == 1 && T >= 512);
-    if (f16) return w8 ? launch_attn16<_Float16, 8>(qkv, mask, out, B, T, H, st) : launch_attn16<_Float16, 4>(qkv, mask, out, B, T, H, st);
-    return w8 ? launch_attn16<bf16_t, 8>(qkv, mask, out, B, T, H, st) : launch_attn16<bf16_t, 4>(qkv, mask, out, B, T, H, st);
+    // the wide form runs its full stages software-pipelined (round 4; switch attn16_pipe = 0: the rolled tile loop).  The 4-wave form keeps
+    // the rolled loop: at 128 keys it is memory-bound and the pipelined body spilled 31 registers (44 -> 54 us on [256, 128, 12 x 64])
+    const bool pipe = tune(TUNE_ATTN16_PIPE) != 0;
+    // (a static priority for waves 4..7 -- guide T5, static form -- on top of the pipelined body: 224.9 vs 227.0 us, nothing; not kept)
+    const KvPages none{};
+    const KvPages& pg = pages ? *pages : none;
+    if (f16) {
+        if (w8) return pipe ? launch_attn16<_Float16, 8, 1>(qkv, mask, out, B, T, H, st, pg) : launch_attn16<_Float16, 8, 0>(qkv, mask, out, B, T, H, st, pg);
+        return launch_attn16<_Float16, 4, 0>(qkv, mask, out, B, T, H, st, pg);
+    }
+    MGEA_REQUIRE(!pg.pool.base, MGEA_EINVAL, "16-bit attention: KV pages are written by the fp16 instantiation only");
+    if (w8) return pipe ? launch_attn16<bf16_t, 8, 1>(qkv, mask, out, B, T, H, st, pg) : launch_attn16<bf16_t, 8, 0>(qkv, mask, out, B, T, H, st, pg);
+    return launch_attn16<bf16_t, 4, 0>(qkv, mask, out, B, T, H, st, pg);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -36,9 +36,10 @@ const TuneEntry kTune[] = {
     {TUNE_DECODER_NOGEMV, "decoder_nogemv", "MGEA_DECODER_NOGEMV", 0},
     {TUNE_DECODER_NOGRAPH, "decoder_nograph", "MGEA_DECODER_NOGRAPH", 0},
     {TUNE_ATTN16_WIDE, "attn16_wide", "MGEA_ATTN16_WIDE", 1},
-    {TUNE_DECODER_PREFILL16_OVERLAP, "decoder_prefill16_overlap", "MGEA_DECODER_PREFILL16_OVERLAP", 1},
+    {TUNE_DECODER_PREFILL16_PAGES, "decoder_prefill16_pages", "MGEA_DECODER_PREFILL16_PAGES", 1},
     {TUNE_DECODER_PREFILL16, "decoder_prefill16", "MGEA_DECODER_PREFILL16", 1},
     {TUNE_HEAD_BALANCED, "head_balanced", "MGEA_HEAD_BALANCED", 1},
+    {TUNE_ATTN16_PIPE, "attn16_pipe", "MGEA_ATTN16_PIPE", 1},
 };
 static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];

@@ -50,10 +50,11 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_BERT_FULL_LAST_LAYER, // 1: the last DistilBERT layer computes every position (as the reference does) instead of K | V for all + the rest for the [CLS] rows only
        TUNE_DECODER_UNFUSED, TUNE_DECODER_NOGEMV, TUNE_DECODER_NOGRAPH,   // read by mgea_decoder_create()
        TUNE_ATTN16_WIDE,          // 16-bit flash attention with 8 waves / 256-key stages: 0 never, 1 from 512 tokens on (default), 2 always
-       TUNE_DECODER_PREFILL16_OVERLAP,   // 1 (default): the KV scatter of the fp16 prefill runs on a side stream under the attention kernel
+       TUNE_DECODER_PREFILL16_PAGES,     // 1 (default): the fp16 prefill writes K | V pages from inside its attention kernel (the rows are in LDS there); 0: a scatter kernel per layer re-reads them from the qkv buffer
        TUNE_DECODER_PREFILL16,    // fp16 engines, big-batch prefill: 0 keep the exact-fp32 kernels (A/B), 1 f16 matrix cores when the batch
                                   // fills the chip (default), 2 whenever the kernels accept the shape (tests)
        TUNE_HEAD_BALANCED,        // 1 (default): the LM head of a 3..64-row decode step on head_balanced_kernel (one workgroup per CU, equal unit counts); 0: the generic skinny kernel
+       TUNE_ATTN16_PIPE,          // 1 (default): the 16-bit flash attention runs full key stages software-pipelined (next tile's Q K^T under this tile's exponentials); 0: rolled loop
        TUNE_COUNT };
 int tune(int key);
 
@@ -255,7 +256,11 @@ int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
                               float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag = nullptr);
 int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
-int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16 = 0);
+// pages (fp16 instantiation only, or NULL): the K | V rows of every key whose mask bit is set also go to the fp16 KV pages of `layer` at
+// position t (decoder prefill into an empty cache: the attention kernel has those rows in LDS anyway)
+struct KvPages { KvPool pool; int layer; const int32_t* page_table; int max_pages; };
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16 = 0,
+                     const KvPages* pages = nullptr);
 
 // fp16 big-batch prefill of the decoder (bf16.hip): embedding rows as fp16 + their (mean, rstd); K | V of fp16 qkv rows -> fp16 KV pages
 int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,

@@ -144,8 +144,6 @@ struct mgea_decoder {
         void *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *w = nullptr;
         float *rowstat = nullptr, *stats_part = nullptr, *ident = nullptr, *vec = nullptr;
         int32_t* mask = nullptr;
-        hipStream_t side = nullptr;        // the KV scatter runs here, under the (compute-bound) attention kernel of the same layer
-        hipEvent_t ev_qkv = nullptr, ev_scatter = nullptr;
         bool weights_ready = false;
         std::vector<int64_t> w_off;      // elements: per layer in_proj', out_proj, fc1', fc2; then the head
     } p16;
@@ -597,9 +595,6 @@ void free_p16(mgea_decoder* h) {
     void* q[] = {p.x0, p.x1, p.qkv, p.att, p.hid, p.w, p.rowstat, p.stats_part, p.ident, p.vec, p.mask};
     for (void* v : q)
         if (v) (void)hipFree(v);
-    if (p.ev_qkv) (void)hipEventDestroy(p.ev_qkv);
-    if (p.ev_scatter) (void)hipEventDestroy(p.ev_scatter);
-    if (p.side) (void)hipStreamDestroy(p.side);
     p = mgea_decoder::Prefill16();
 }
 
@@ -687,15 +682,9 @@ int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int 
     const float *id_g = p.ident + p.rows * 2, *id_b = id_g + C;
     PROF(PC_ROWOP, launch_dec_embed_f16(ids, lens, h->ctx_len, h->w(T_TOK), h->w(T_POS), xc, p.rowstat, lens ? p.mask : nullptr, c.ln_eps, B, T,
                                         C, V, c.seq_len, c.pos_mode == MGEA_POS_ABSOLUTE, h->err_flag, st));
-    // The KV scatter of a layer (HBM-bound: reads K | V of qkv, writes the pages) has no consumer inside the prefill, and the attention
-    // kernel next to it is compute-bound with registers and LDS to spare per CU: the scatter runs on a side stream between two events --
-    // after the layer's QKV GEMM, before the next layer's QKV GEMM overwrites qkv (and before the call returns to the caller's stream).
-    const bool overlap = tune(TUNE_DECODER_PREFILL16_OVERLAP) != 0;
-    if (overlap && !p.side) {
-        MGEA_CHECK_HIP(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
-        MGEA_CHECK_HIP(hipEventCreateWithFlags(&p.ev_qkv, hipEventDisableTiming));
-        MGEA_CHECK_HIP(hipEventCreateWithFlags(&p.ev_scatter, hipEventDisableTiming));
-    }
+    // K | V of the real tokens reach the fp16 KV pages from inside the attention kernel of their layer (bf16.hip: it has those rows in LDS
+    // anyway; round 3 ran a scatter kernel per layer that re-read them from the qkv buffer, on a side stream under the attention).  Only a
+    // last block that stops at its K | V (kv_only_last: no attention runs) still uses the scatter kernel.
     for (int l = 0; l < c.n_layer; ++l) {
         const bool last = l + 1 == c.n_layer;
         if (last && kv_only_last) {
@@ -708,15 +697,13 @@ int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int 
         }
         const BfEpiLn q{p.rowstat, h->p16_vec(l, 0), nullptr, nullptr, nullptr};
         PROF(PC_GEMM, launch_gemm_bf16(xc, C, h->p16_w(4 * l + 0), C, h->p16_vec(l, 1), nullptr, p.qkv, 3 * C, M, 3 * C, C, 3, st, nullptr, &q, 1));
-        if (overlap) {
-            MGEA_CHECK_HIP(hipEventRecord(p.ev_qkv, st));
-            MGEA_CHECK_HIP(hipStreamWaitEvent(p.side, p.ev_qkv, 0));
-            MGEA_TRY(launch_kv_scatter_f16(p.qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, B, T, C, p.side));
-            MGEA_CHECK_HIP(hipEventRecord(p.ev_scatter, p.side));
+        const KvPages pages{h->kv, l, h->page_table, h->max_pages};
+        if (tune(TUNE_DECODER_PREFILL16_PAGES)) {
+            PROF(PC_ATTN_DENSE, launch_attn_bf16(p.qkv, lens ? p.mask : nullptr, p.att, B, T, c.n_head, h->dh, st, 1, &pages));
         } else {
             PROF(PC_ROWOP, launch_kv_scatter_f16(p.qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, B, T, C, st));
+            PROF(PC_ATTN_DENSE, launch_attn_bf16(p.qkv, lens ? p.mask : nullptr, p.att, B, T, c.n_head, h->dh, st, 1));
         }
-        PROF(PC_ATTN_DENSE, launch_attn_bf16(p.qkv, lens ? p.mask : nullptr, p.att, B, T, c.n_head, h->dh, st, 1));
         const BfEpiLn o{p.ident, nullptr, id_g, id_b, p.stats_part};
         PROF(PC_GEMM, launch_gemm_bf16(p.att, C, h->p16_w(4 * l + 1), C, h->lw(l, L_OUTB), xc, xo, C, M, C, C, 5, st, nullptr, &o, 1));
         PROF(PC_ROWOP, launch_ln_rowstat(p.stats_part, p.rowstat, M, npart, C, c.ln_eps, st));
@@ -726,7 +713,6 @@ int run_prefill16(mgea_decoder* h, const int32_t* ids, const int32_t* lens, int 
         GemmBf16Info rv{0, 0, 1};                            // reads FC1's big output: walk the tiles backwards (bf16.hip)
         PROF(PC_GEMM, launch_gemm_bf16(p.hid, F, h->p16_w(4 * l + 3), F, h->lw(l, L_FC2B), xo, xc, C, M, C, F, 5, st, &rv, &f2, 1));
         if (!last) PROF(PC_ROWOP, launch_ln_rowstat(p.stats_part, p.rowstat, M, npart, C, c.ln_eps, st));
-        if (overlap) MGEA_CHECK_HIP(hipStreamWaitEvent(st, p.ev_scatter, 0));   // qkv may be overwritten / the pages are the caller's from here
     }
     if (logits_out)
         PROF(PC_GEMM, launch_gemm_bf16(xc, C, h->p16_w(4 * c.n_layer), C, h->head_b(), nullptr, logits_out, V, M, V, C, 6, st, nullptr, nullptr, 1));

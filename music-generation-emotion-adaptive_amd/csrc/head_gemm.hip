@@ -31,7 +31,8 @@ namespace mgea {
 namespace {
 constexpr int HB_PITCH = 20;   // floats per LDS row of a partial tile (16 + 4: the 16 rows of one ds_write_b128 start in different banks)
 
-template <int BASE, int NCH, bool F16>
+// TS (tools/head_phases.py only, dbg bit 21; never in an engine): lane 0 of every wave writes 100 MHz stamps of its phases to stats_out
+template <int BASE, int NCH, bool F16, bool TS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_balanced_kernel(SkinnyArgs a, int n_extra) {
     constexpr int NU = 4 * BASE + 1;                 // units per workgroup (the last one is the extra / dummy unit)
     constexpr int NS = 4 * (BASE + 1);               // (max, argmax) slots per row: 4 column quads per column tile
@@ -48,6 +49,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rx = has_x ? (wg & 3) : 0;                               // its row tile
     const unsigned mk0 = rx == 0 ? ~0u : 0u, mk1 = rx == 1 ? ~0u : 0u, mk2 = rx == 2 ? ~0u : 0u, mk3 = rx == 3 ? ~0u : 0u;
     const int kbeg = wave * 32 * NCH, chunks = a.K >> 5;
+    long long* ts = TS ? reinterpret_cast<long long*>(a.stats_out + 2 * 64 * (int64_t)gridDim.x) + ((int64_t)blockIdx.x * 8 + wave) * 8 : nullptr;   // behind the (max, argmax) partials
+#define HB_TS(i) do { if (TS && lane == 0) ts[i] = wall_clock64(); } while (0)
+    HB_TS(0);
 
     // ---- every operand load of the wave, chunk-major (chunk 0 of everything first: the MFMAs of chunk 0 run under chunk 1's flight)
     float4 wf[BASE + 1][NCH][2], af[4][NCH][2];
@@ -72,6 +76,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             af[r][ch][1] = ld4(ap + 256);
         }
     }
+    HB_TS(1);
+    if (TS) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((F16 ? BASE + 1 : 2 * (BASE + 1)) + 8) : "memory"); HB_TS(2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); HB_TS(3); }
     __builtin_amdgcn_sched_barrier(0);   // every load above is in flight before the first MFMA (hipcc otherwise feeds them in among the
                                          // MFMAs two at a time to save registers: a chain of dependent round trips)
     f32x4 acc[NU];
@@ -125,11 +131,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return b;
     };
     const float4 bias0 = load_bias(item_n(tid));
+    if (TS) { __builtin_amdgcn_sched_barrier(0); HB_TS(4); }
     // ---- partial tiles -> LDS: D[i = column 4 g + reg][j = row c]
 #pragma unroll
     for (int u = 0; u < NU; ++u)
         *reinterpret_cast<float4*>(&red[((wave * NU + u) * 16 + c) * HB_PITCH + 4 * g]) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
     __syncthreads();
+    HB_TS(5);
 
     // ---- epilogue: item = (unit u, local row lr, column quad q); 8 partials summed in wave order (deterministic)
     for (int it = tid; it < NU * 64; it += 512) {
@@ -200,6 +208,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         a.pmax_val[(int64_t)tid * G + wg] = best;
         a.pmax_idx[(int64_t)tid * G + wg] = bi;
     }
+    if (TS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); HB_TS(6); }
+#undef HB_TS
 }
 
 struct HeadPlan { int G, base, n_extra, nch; };
@@ -244,7 +254,20 @@ static int launch_head_t(const SkinnyArgs& a, const HeadPlan& p, hipStream_t st)
 // returns MGEA_OK after launching, or 1 when the shape is not this kernel's (the caller falls back to gemm_skinny_kernel)
 int launch_head_balanced(const SkinnyArgs& a, hipStream_t st) {
     HeadPlan p;
-    if (a.ln_c1 || a.dbg || !head_plan(a.M, a.N, a.K, &p)) return 1;
+    if (a.ln_c1 || (a.dbg & ~(1 << 21)) || !head_plan(a.M, a.N, a.K, &p)) return 1;
+    if (a.dbg & (1 << 21)) {    // tools/head_phases.py: the stamped build of the benchmark's instantiation
+        if (p.base != 2 || p.nch != 2 || a.w_f16 || !a.stats_out) return 1;
+        constexpr int NU = 9, NS = 12;
+        int shmem = (8 * NU * 16 * HB_PITCH + 64 * NS * 2) * (int)sizeof(float);
+        if (shmem < 84 * 1024) shmem = 84 * 1024;
+        DeviceInfo di;
+        MGEA_TRY(device_info(&di));
+        static uint64_t ts_done = 0;
+        MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&head_balanced_kernel<2, 2, false, true>), shmem, di.dev, &ts_done));
+        hipLaunchKernelGGL((head_balanced_kernel<2, 2, false, true>), dim3(p.G), dim3(512), shmem, st, a, p.n_extra);
+        MGEA_CHECK_HIP(hipGetLastError());
+        return MGEA_OK;
+    }
 #define MGEA_HEAD_GO(B_, N_)                                                              \
     if (p.base == B_ && p.nch == N_)                                                      \
         return a.w_f16 ? launch_head_t<B_, N_, true>(a, p, st) : launch_head_t<B_, N_, false>(a, p, st);

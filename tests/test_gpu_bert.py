@@ -86,7 +86,7 @@ def test_device_resident_ids_outside_the_vocabulary_are_reported(dtype, tune):
     clamp such ids and set the engine's sticky flag, which id_errors() turns into the same IndexError (the check had been
     dropped without a replacement).  Both embedding kernels: the fp32 one and, on a bf16 engine forced onto its 16-bit path, the bf16 one."""
     from mgea.bert import BertEngine
-    sd = synth.distilbert_state_dict(5, 100, 32, 128, 2, 512)
+    sd = synth.distilbert_state_dict(5, 100, 128, 128, 2, 512)
     eng = BertEngine(sd, n_heads=2, max_tokens=1024, dtype=dtype)
     B, S = (8, 128) if dtype == "bf16" else (2, 8)       # bf16 engines take their 16-bit kernels from 512 tokens on
     good = torch.randint(1, 100, (B, S), dtype=torch.int32)

@@ -40,13 +40,15 @@ for s in $STEPS; do
     bertrev)   run bertrev 300 python3 tools/bert_ab.py bf16_gemm_reverse 0 1 || exit 1 ;;
     berttrace) rm -rf /tmp/bt_$TAG; run berttrace 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bt_$TAG -- python3 tools/bert_prof.py bf16 || exit 1
                f=$(find /tmp/bt_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/bert_layer_times.py $f > $OUT/bert_layer_times.txt; cat $OUT/bert_layer_times.txt | head -70 ;;
-    prefillab) run prefillab 300 python3 tools/prefill_ab.py decoder_prefill16_overlap 0 1 || exit 1 ;;
+    prefillab) run prefillab 300 python3 tools/prefill_ab.py decoder_prefill16_pages 0 1 || exit 1 ;;
     attnwide)  run attnwide 300 python3 tools/prefill_ab.py attn16_wide 0 1 || exit 1 ;;
     attnstamps) run attnstamps 300 python3 tools/attn_stamps.py || exit 1 ;;
     bertph)    run bertph 300 python3 tools/bert_ab.py bf16_gemm_phases 4 2 1 || exit 1 ;;
     newtests)  run newtests 900 python3 -m pytest tests/test_gpu_decoder.py tests/test_gpu_ops.py tests/test_gpu_bf16.py tests/test_gpu_bert.py -x -q -m gpu -s -k "long or half_tile_tail_whose or odd_batch or lm_head or device_resident" || exit 1 ;;
     prefillprof) rm -rf /tmp/pp_$TAG; run prefillprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_$TAG -- python3 tools/prefill_bench.py ${PREFILL_DTYPE:-f32} logits || exit 1
                f=$(find /tmp/pp_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prefill_${PREFILL_DTYPE:-f32}_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
+    attn16ab)  run attn16ab 300 python3 tools/attn16_ab.py ${AB_SWITCH:-attn16_pipe} ${AB_VALUES:-0 1} || exit 1 ;;
+    attntests) run attntests 600 python3 -m pytest tests/test_gpu_bf16.py tests/test_gpu_f16.py -x -q -m gpu -k "attention or prefill" || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """A/B of a library switch on the fp16 matrix-core prefill of Decoder-S [64, 1024] (cache fill, logits dropped), variants interleaved in
-one process:  python3 tools/prefill_ab.py decoder_prefill16_overlap 0 1"""
+one process:  python3 tools/prefill_ab.py decoder_prefill16_pages 0 1"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "music-generation-emotion-adaptive_amd"))
 import torch
 from mgea import _lib, synth
 from mgea.decoder import DecoderEngine
-name = sys.argv[1] if len(sys.argv) > 1 else "decoder_prefill16_overlap"
+name = sys.argv[1] if len(sys.argv) > 1 else "decoder_prefill16_pages"
 vals = [int(v) for v in sys.argv[2:]] or [0, 1]
 B, T = 64, 1024
 sd = synth.decoder_state_dict(0, 8324, 1024, 512, 6)
