@@ -38,8 +38,13 @@ extern "C" {
 #define MGEA_DTYPE_F32   0   /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define MGEA_DTYPE_BF16  1   /* DistilBERT perf mode: bf16 weights + activations, fp32 accumulate (bf16 MFMA); calls of fewer than 512
                                 tokens (one text per request) run on the exact-fp32 kernels of the same engine */
-#define MGEA_DTYPE_F16   2   /* decoder perf mode: fp16 projection matrices + fp16 KV pages, fp32 accumulate (f16 MFMA),
-                                fp32 residual stream / LayerNorm / softmax / logits */
+#define MGEA_DTYPE_F16   2   /* decoder perf mode: fp16 projection matrices + fp16 KV pages, fp32 accumulate (f16 MFMA).  DECODE steps and
+                                prefills of up to 512 (row, token) pairs keep the residual stream, LayerNorm, softmax and logits in fp32.
+                                A BIG prefill into an empty cache (>= 256 tiles of 256 x 256: e.g. [64, 1024]; switch decoder_prefill16)
+                                runs on the f16 matrix cores with fp16 activations between the GEMMs -- the residual stream too, saturated
+                                at +-65504 where it is written; accumulation, LayerNorm statistics, softmax and logits stay fp32.  Checked
+                                against the oracle on synthetic weights only (tests/test_gpu_f16.py); a trained checkpoint whose residual
+                                stream leaves the fp16 range would be clipped there: parity on trained weights is unpinned. */
 
 #define MGEA_BLOCK_PRELN_GELU  0  /* api_cache.py:51-74 GPTBlock (KV-cache model, the default) */
 #define MGEA_BLOCK_POSTLN_RELU 1  /* generate_music/generate.py:25-35 nn.TransformerEncoder twin */
@@ -188,6 +193,15 @@ int mgea_bert_destroy(mgea_bert* h);
  * bert_full_last_layer = 1 computes every position). */
 int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
                       int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
+/* PACKED forward (bf16 engines): the real tokens of the B sequences back to back instead of [B, S] rows padded to the batch's longest
+ * prompt (what the tokenizer call of emotion_analysis/inference.py:16 -- padding=True -- hands to the model).  ids_dev / pos_ids_dev
+ * [n_tokens] int32 (token id; position of the token inside its sequence), cu_seqlens_dev [B + 1] int32 (sequence b = rows cu[b] ..
+ * cu[b + 1] - 1; cu[0] = 0, cu[B] = n_tokens), max_len = the longest sequence (<= 256).  Every row-wise GEMM, LayerNorm statistic
+ * and attention tile then runs on real tokens only; same logits as the padded call with the corresponding prefix mask (a row's results
+ * do not depend on the other rows of the batch, and a sequence attends to exactly its own keys in both forms).  Needs at least 512
+ * tokens (the 16-bit kernels' routing threshold): smaller calls belong to mgea_bert_forward. */
+int mgea_bert_forward_packed(mgea_bert* h, const int32_t* ids_dev, const int32_t* pos_ids_dev, const int32_t* cu_seqlens_dev, int32_t B,
+                             int32_t n_tokens, int32_t max_len, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
 /* Token ids handed over as DEVICE memory are not read back before the forward (that would put a host sync in front of every call):
  * an id outside [0, vocab) -- nn.Embedding raises IndexError in the reference (emotion_analysis/inference.py:16-17) -- is clamped by the
  * embedding kernel and recorded in a sticky device flag.  This call synchronises `stream`, returns the flags (bit 0 = an id was clamped
@@ -198,7 +212,7 @@ int mgea_bert_error_flags(mgea_bert* h, int32_t* flags_out, void* stream);
  * a ring kernel / the 128 x 128 kernel, [5] persistent launches that cut their left-over tiles into 128-row halves,
  * [6] LayerNorm kernel launches, [7] 1 when the last layer ran for the [CLS] rows only (K | V of every position, the rest on B rows:
  * the classifier reads nothing else; switch bert_full_last_layer = 1 computes every position), [8 + e] bf16 GEMM launches with
- * epilogue e (0..5); others 0. */
+ * epilogue e (0..5), [14] rows the GEMMs ran on (padded call: B S; packed call: the real tokens); others 0. */
 int mgea_bert_stats(mgea_bert* h, int64_t* out /* [16] */);
 
 /* W[out,in] += scale * B[out,r] @ A[r,in] in place (peft LoRA fold, W' = W + (alpha/r) B A;

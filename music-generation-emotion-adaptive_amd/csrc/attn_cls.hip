@@ -32,11 +32,14 @@ template <> struct Row8<__bf16> {
 
 template <typename T, int DH>
 __global__ __launch_bounds__(64) void attn_cls_kernel(const float* __restrict__ q, const T* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                     float* __restrict__ out, int S, int H, float scale) {
+                                                     float* __restrict__ out, int S_pad, int H, float scale, const int32_t* __restrict__ cu) {
     constexpr int C = DH / 8, G = 64 / C, NI = 16, BLK = NI * G;    // keys per block of 16 iterations: 128 (DH 64) / 256 (DH 32)
     const int lane = threadIdx.x, c = lane % C, g = lane / C;
     const int b = blockIdx.x / H, hd = blockIdx.x % H, D = H * DH;
-    const T* kbase = qkv + (int64_t)b * S * 3 * D + D + hd * DH + c * 8;     // K of key t: kbase + t * 3 D; V: + D
+    // packed input (cu != NULL): the sequence's rows are cu[b] .. cu[b + 1] - 1, all of them real tokens (no mask)
+    const int64_t row0 = cu ? (int64_t)cu[b] : (int64_t)b * S_pad;
+    const int S = cu ? cu[b + 1] - cu[b] : S_pad;
+    const T* kbase = qkv + row0 * 3 * D + D + hd * DH + c * 8;                // K of key t: kbase + t * 3 D; V: + D
     float qv[8];
     {
         const float4 q0 = ld4(q + (int64_t)b * D + hd * DH + c * 8), q1 = ld4(q + (int64_t)b * D + hd * DH + c * 8 + 4);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(64) void attn_cls_kernel(const float* __restrict__ 
         for (int i = 0; i < NI; ++i) {
             const int t = t0 + i * G + g;
             ok[i] = t < S;
-            if (ok[i] && mask) ok[i] = mask[(int64_t)b * S + t] != 0;
+            if (ok[i] && mask) ok[i] = mask[(int64_t)b * S_pad + t] != 0;
             Row8<T>::load(kbase + (int64_t)(t < S ? t : S - 1) * 3 * D, kv[i]);     // clamped: loaded, not used
         }
         float cm = -INFINITY;
@@ -102,17 +105,19 @@ __global__ __launch_bounds__(64) void attn_cls_kernel(const float* __restrict__ 
     }
 }
 
-int launch_attn_cls(const float* q, const void* qkv, int qkv_bf16, const int32_t* mask, float* out, int B, int S, int H, int dh, hipStream_t st) {
+int launch_attn_cls(const float* q, const void* qkv, int qkv_bf16, const int32_t* mask, float* out, int B, int S, int H, int dh, hipStream_t st,
+                    const int32_t* cu) {
+    MGEA_REQUIRE(!(cu && mask), MGEA_EINVAL, "attn_cls: packed rows carry no key mask");
     const float scale = 1.0f / sqrtf((float)dh);
     const dim3 grid(B * H), block(64);
     if (qkv_bf16) {
         MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "attn_cls: bf16 keys need head_dim 64");
-        hipLaunchKernelGGL((attn_cls_kernel<__bf16, 64>), grid, block, 0, st, q, (const __bf16*)qkv, mask, out, S, H, scale);
+        hipLaunchKernelGGL((attn_cls_kernel<__bf16, 64>), grid, block, 0, st, q, (const __bf16*)qkv, mask, out, S, H, scale, cu);
     } else if (dh == 64) {
-        hipLaunchKernelGGL((attn_cls_kernel<float, 64>), grid, block, 0, st, q, (const float*)qkv, mask, out, S, H, scale);
+        hipLaunchKernelGGL((attn_cls_kernel<float, 64>), grid, block, 0, st, q, (const float*)qkv, mask, out, S, H, scale, cu);
     } else {
         MGEA_REQUIRE(dh == 32, MGEA_EINVAL, "attn_cls: head_dim %d not built (32 or 64)", dh);
-        hipLaunchKernelGGL((attn_cls_kernel<float, 32>), grid, block, 0, st, q, (const float*)qkv, mask, out, S, H, scale);
+        hipLaunchKernelGGL((attn_cls_kernel<float, 32>), grid, block, 0, st, q, (const float*)qkv, mask, out, S, H, scale, cu);
     }
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;

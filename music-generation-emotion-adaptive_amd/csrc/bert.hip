@@ -70,6 +70,7 @@ struct mgea_bert {
     // (persistent / ring / small), persistent launches that cut their tail tiles in halves, by epilogue (0..5); LayerNorm kernels
     int64_t n_forwards = 0, last_fold = 0, last_persistent = 0, last_ring = 0, last_small = 0, last_half_tiles = 0, last_ln_kernels = 0, last_cls_only = 0;
     int64_t last_epi[6] = {0, 0, 0, 0, 0, 0};
+    int64_t last_rows = 0;         // rows the last forward ran its GEMMs on (padded: B S; packed: the real tokens)
     int32_t* err_flag = nullptr;   // sticky device flags (bit 0: a token id outside the vocabulary was clamped), as the decoder's
     // bf16 mode, folded-LayerNorm pipeline (big batches: every GEMM on the persistent kernel): W diag(gamma) copies, c1 / c2 vectors,
     // per-tile row sums and the two (mean, rstd) tables
@@ -189,16 +190,25 @@ int mgea_bert_create(const mgea_bert_config* cfg, const float* arena_dev, mgea_b
     return MGEA_OK;
 }
 
-int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t S,
-                      float* logits_out_dev, int32_t* argmax_out_dev, void* stream) {
-    MGEA_REQUIRE(h && ids_dev, MGEA_EINVAL, "bert_forward: NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+// The forward behind both entry points.  Padded input: ids [B, S] (+ key mask), M = B S rows.  PACKED input (cu != NULL, round 4): the
+// real tokens of the B sequences back to back -- ids / pos_ids [M], sequence b = rows cu[b] .. cu[b + 1] - 1, S = the longest sequence --
+// so that the row-wise GEMMs, the LayerNorm statistics and the attention run on sum(lengths) rows instead of B x S: with the reference's
+// tokenizer padding a batch to its longest prompt (emotion_analysis/inference.py:16, padding=True) 44 % of the [256, 128] bench batch is
+// padding whose rows nobody reads.  Same logits: a row's GEMM / LayerNorm results do not depend on which other rows are in the batch, and a
+// sequence attends to exactly its own real keys in both forms.
+static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t S, int64_t M64,
+                             const int32_t* cu, const int32_t* pos_ids, float* logits_out_dev, int32_t* argmax_out_dev, hipStream_t st) {
     const auto& c = h->cfg;
     MGEA_REQUIRE(B > 0 && S > 0, MGEA_EINVAL, "bert_forward: bad shape B=%d S=%d", B, S);
     MGEA_REQUIRE(S <= c.max_pos, MGEA_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, c.max_pos);
-    MGEA_REQUIRE((int64_t)B * S <= c.max_tokens, MGEA_ECAPACITY, "B*S = %lld exceeds max_tokens %d", (long long)B * S, c.max_tokens);
-    const int M = B * S, D = c.dim, Hd = c.hidden, NL = c.num_labels, dh = D / c.n_heads;
+    MGEA_REQUIRE(M64 > 0 && M64 <= c.max_tokens, MGEA_ECAPACITY, "%lld tokens exceed max_tokens %d", (long long)M64, c.max_tokens);
+    const int M = (int)M64, D = c.dim, Hd = c.hidden, NL = c.num_labels, dh = D / c.n_heads;
+    if (cu)
+        MGEA_REQUIRE(c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS && !mask_dev && pos_ids && S <= 256 && dh == 64, MGEA_EINVAL,
+                     "bert_forward_packed: needs a bf16 engine, at least %d tokens, sequences of at most 256 tokens (got %d tokens, longest %d)",
+                     BF16_MIN_TOKENS, M, S);
     auto gemm = [&](const float* A, int lda, const float* W, int m, int n, int k, int* Sout) -> int {
         const int s = pick_split_k(m, n, k, h->slab_cap);
         MGEA_REQUIRE((int64_t)s * slab_floats(m, n) <= h->slab_cap, MGEA_ECAPACITY, "internal: bert slab workspace too small");
@@ -228,7 +238,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
         float *cq = cls, *cctx = cls + (int64_t)B * D, *chid = cls + (int64_t)2 * B * D;
         MGEA_TRY(gemm(h->pooled, D, h->lw(l, BL_QKVW), B, D, D, &Sk));                     // q = x W_q^T + b_q (rows 0..D-1 of the stacked matrix)
         MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_QKVB), cq, D, B, D, ACT_NONE, st));
-        MGEA_TRY(launch_attn_cls(cq, kv, kv_bf16, mask_dev, cctx, B, S, c.n_heads, dh, st));
+        MGEA_TRY(launch_attn_cls(cq, kv, kv_bf16, mask_dev, cctx, B, S, c.n_heads, dh, st, cu));
         MGEA_TRY(gemm(cctx, D, h->lw(l, BL_OUTW), B, D, D, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(B, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->pooled, nullptr,
                                     h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, B, D, 1, st));
@@ -259,8 +269,10 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             h->last_epi[epi] += 1;
             return MGEA_OK;
         };
-        MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
-                                           S, D, c.vocab, st, h->err_flag));
+        if (cu) MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, M, 1, D, c.vocab, st,
+                                                   h->err_flag, pos_ids));
+        else MGEA_TRY(launch_bert_embed_ln_bf16(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->hb, B,
+                                                S, D, c.vocab, st, h->err_flag));
         // Folded-LayerNorm pipeline: when every GEMM of a layer runs on the persistent 256 x 256 kernel (big batches), no LayerNorm
         // kernel runs at all.  The residual GEMMs write the RAW sums (x + sublayer(x)) and per-tile row sums; a 1-launch reduction
         // turns those into (mean, rstd) per row; the consumers apply the LayerNorm themselves: the next GEMM as rstd (A W'^T - mean
@@ -282,11 +294,11 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
                     if (first) {
                         MGEA_TRY(bgemm(h->hb, D, (const char*)wb(l, BL_QKVW) + kv_off, D, h->lw(l, BL_QKVB) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M,
                                        2 * D, D, 0));
-                        MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+                        MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st, cu));
                     } else {
                         BfEpiLn q{h->rowstat_out, h->qkvc(l, 0) + D, nullptr, nullptr, nullptr};
                         MGEA_TRY(bgemm(h->hb, D, h->qkvf(l) + kv_off, D, h->qkvc(l, 1) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M, 2 * D, D, 3, &q));
-                        MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(l - 1, BL_OLNW), h->lw(l - 1, BL_OLNB), h->pooled, B, S, D, st));
+                        MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(l - 1, BL_OLNW), h->lw(l - 1, BL_OLNB), h->pooled, B, S, D, st, cu));
                     }
                     MGEA_TRY(cls_tail(l, h->qkvb, 1));
                     break;
@@ -297,7 +309,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
                     BfEpiLn q{h->rowstat_out, h->qkvc(l, 0), nullptr, nullptr, nullptr};
                     MGEA_TRY(bgemm(h->hb, D, h->qkvf(l), D, h->qkvc(l, 1), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 3, &q));
                 }
-                MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
+                MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st, 0, nullptr, cu));
                 // out-proj + LayerNorm_out(l-1)(raw hb) as the residual (layer 0: hb is already normalised) -> raw tmpb + row sums
                 BfEpiLn o{first ? h->ident : h->rowstat_out, nullptr, first ? id_g : h->lw(l - 1, BL_OLNW), first ? id_b : h->lw(l - 1, BL_OLNB),
                           h->stats_part};
@@ -312,18 +324,18 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             }
             if (!cls_last)
                 MGEA_TRY(launch_gather_cls_ln_bf16(h->hb, h->rowstat_out, h->lw(c.n_layers - 1, BL_OLNW), h->lw(c.n_layers - 1, BL_OLNB), h->pooled, B, S,
-                                                   D, st));
+                                                   D, st, cu));
         } else {
         for (int l = 0; l < c.n_layers; ++l) {
             if (cls_last && l == last) {
                 MGEA_TRY(bgemm(h->hb, D, (const char*)wb(l, BL_QKVW) + kv_off, D, h->lw(l, BL_QKVB) + D, nullptr, (char*)h->qkvb + D * 2, 3 * D, M, 2 * D,
                                D, 0));
-                MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+                MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st, cu));
                 MGEA_TRY(cls_tail(l, h->qkvb, 1));
                 break;
             }
             MGEA_TRY(bgemm(h->hb, D, wb(l, BL_QKVW), D, h->lw(l, BL_QKVB), nullptr, h->qkvb, 3 * D, M, 3 * D, D, 0));
-            MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st));
+            MGEA_TRY(launch_attn_bf16(h->qkvb, mask_dev, h->ctxb, B, S, c.n_heads, dh, st, 0, nullptr, cu));
             MGEA_TRY(bgemm(h->ctxb, D, wb(l, BL_OUTW), D, h->lw(l, BL_OUTB), h->hb, h->tmpb, D, M, D, D, 2));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), h->hb, M, D, c.ln_eps, st));
             h->last_ln_kernels += 2;
@@ -331,7 +343,7 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
             MGEA_TRY(bgemm(h->ffnb, Hd, wb(l, BL_L2W), Hd, h->lw(l, BL_L2B), h->hb, h->tmpb, D, M, D, Hd, 2));
             MGEA_TRY(launch_layernorm_bf16(h->tmpb, h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), h->hb, M, D, c.ln_eps, st));
         }
-        if (!cls_last) MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st));
+        if (!cls_last) MGEA_TRY(launch_gather_cls_bf16(h->hb, h->pooled, B, S, D, st, cu));
         }
     } else {
     h->last_cls_only = cls_last ? 1 : 0;
@@ -382,7 +394,25 @@ int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_
     MGEA_TRY(launch_logits_argmax(h->slabs, Sk, slab_floats(B, NL), (int)slab_ld(NL), h->hw(3), logits_out_dev, B, NL,
                                   argmax_out_dev, st));
     h->n_forwards += 1;
+    h->last_rows = M;
     return MGEA_OK;
+}
+
+extern "C" {
+
+int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t S,
+                      float* logits_out_dev, int32_t* argmax_out_dev, void* stream) {
+    MGEA_REQUIRE(h && ids_dev, MGEA_EINVAL, "bert_forward: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return bert_forward_impl(h, ids_dev, mask_dev, B, S, (int64_t)B * S, nullptr, nullptr, logits_out_dev, argmax_out_dev, (hipStream_t)stream);
+}
+
+int mgea_bert_forward_packed(mgea_bert* h, const int32_t* ids_dev, const int32_t* pos_ids_dev, const int32_t* cu_seqlens_dev, int32_t B,
+                             int32_t n_tokens, int32_t max_len, float* logits_out_dev, int32_t* argmax_out_dev, void* stream) {
+    MGEA_REQUIRE(h && ids_dev && pos_ids_dev && cu_seqlens_dev, MGEA_EINVAL, "bert_forward_packed: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return bert_forward_impl(h, ids_dev, nullptr, B, max_len, n_tokens, cu_seqlens_dev, pos_ids_dev, logits_out_dev, argmax_out_dev,
+                             (hipStream_t)stream);
 }
 
 int mgea_bert_error_flags(mgea_bert* h, int32_t* flags_out, void* stream) {
@@ -404,6 +434,7 @@ int mgea_bert_stats(mgea_bert* h, int64_t* out) {
     out[0] = h->n_forwards; out[1] = h->last_fold; out[2] = h->last_persistent; out[3] = h->last_ring; out[4] = h->last_small;
     out[5] = h->last_half_tiles; out[6] = h->last_ln_kernels; out[7] = h->last_cls_only;
     for (int e = 0; e < 6; ++e) out[8 + e] = h->last_epi[e];
+    out[14] = h->last_rows;
     return MGEA_OK;
 }
 

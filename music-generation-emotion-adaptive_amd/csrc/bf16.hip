@@ -1092,6 +1092,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(const T* __restrict__
                             r = r + bet2[q];                           // the bias
                         }
                         x = x + r;
+                        if constexpr (!X16<T>::is_bf16) {   // fp16 residual stream of the decoder's big prefill: saturate instead of inf -> NaN
+                            x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);   // (bf16 has fp32's range)
+                            x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+                        }
                         const v2 o = {(T)x[0], (T)x[1]};
                         vw[q] = __builtin_bit_cast(unsigned, o);
                     }
@@ -1525,14 +1529,14 @@ int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float*
 
 // CLS rows (row b * S) of the RAW last-layer output -> LayerNorm with the row's (mean, rstd) -> fp32 [B, D]
 __global__ void gather_cls_ln_bf16_kernel(const bf16_t* __restrict__ h, const float* __restrict__ rowstat, const float* __restrict__ g,
-                                          const float* __restrict__ be, float* __restrict__ out, int S, int D) {
-    const int64_t row = (int64_t)blockIdx.x * S;
+                                          const float* __restrict__ be, float* __restrict__ out, int S, int D, const int32_t* __restrict__ cu) {
+    const int64_t row = cu ? (int64_t)cu[blockIdx.x] : (int64_t)blockIdx.x * S;      // the [CLS] row of sequence b (packed input: its first row)
     const float mean = rowstat[row * 2], rstd = rowstat[row * 2 + 1];
     for (int d = threadIdx.x; d < D; d += blockDim.x) out[(int64_t)blockIdx.x * D + d] = fmaf(((float)h[row * D + d] - mean) * rstd, g[d], be[d]);
 }
 int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* g, const float* be, float* out, int B, int S, int D,
-                              hipStream_t st) {
-    hipLaunchKernelGGL(gather_cls_ln_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, rowstat, g, be, out, S, D);
+                              hipStream_t st, const int32_t* cu) {
+    hipLaunchKernelGGL(gather_cls_ln_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, rowstat, g, be, out, S, D, cu);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -1625,11 +1629,11 @@ __global__ __launch_bounds__(256) void bert_embed_ln_bf16_kernel(const int32_t* 
                                                                 const float* __restrict__ pos, const float* __restrict__ lnw,
                                                                 const float* __restrict__ lnb, float eps,
                                                                 bf16_t* __restrict__ h, int M, int S, int D, int vocab,
-                                                                int32_t* __restrict__ err_flag) {
+                                                                int32_t* __restrict__ err_flag, const int32_t* __restrict__ pos_ids) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const int t = (int)(row % S);
+    const int t = pos_ids ? pos_ids[row] : (int)(row % S);      // packed input carries each row's position in its sequence
     int id = ids[row];
     if ((id < 0 || id >= vocab) && err_flag && lane == 0) atomicOr(err_flag, 1);   // clamped + reported (mgea_bert_error_flags)
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -1665,21 +1669,22 @@ __global__ __launch_bounds__(256) void bert_embed_ln_bf16_kernel(const int32_t* 
     }
 }
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
-                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag) {
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag, const int32_t* pos_ids) {
     MGEA_REQUIRE(D % 4 == 0 && D <= 2048, MGEA_EINVAL, "bf16 embed: dim=%d must be a multiple of 4 and <= 2048", D);
+    // (packed input: B = the number of rows, S = 1)
     hipLaunchKernelGGL(bert_embed_ln_bf16_kernel, dim3(ceil_div(B * S, 4)), dim3(256), 0, st, ids, word, pos, lnw, lnb, eps,
-                       (bf16_t*)h, B * S, S, D, vocab, err_flag);
+                       (bf16_t*)h, B * S, S, D, vocab, err_flag, pos_ids);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
 
 // CLS rows (row b*S) of a bf16 [B*S, D] matrix -> fp32 [B, D] for the small fp32 classifier head
-__global__ void gather_cls_bf16_kernel(const bf16_t* __restrict__ h, float* __restrict__ out, int S, int D) {
-    const int64_t b = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) out[b * D + d] = (float)h[b * S * (int64_t)D + d];
+__global__ void gather_cls_bf16_kernel(const bf16_t* __restrict__ h, float* __restrict__ out, int S, int D, const int32_t* __restrict__ cu) {
+    const int64_t b = blockIdx.x, row = cu ? (int64_t)cu[b] : b * S;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[b * D + d] = (float)h[row * D + d];
 }
-int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st) {
-    hipLaunchKernelGGL(gather_cls_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, out, S, D);
+int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st, const int32_t* cu) {
+    hipLaunchKernelGGL(gather_cls_bf16_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)h, out, S, D, cu);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -1725,7 +1730,7 @@ __device__ __forceinline__ float quad_max(float x) {
 template <typename E, int NW, int PIPE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mask, E* __restrict__ out, int T, int H,
-                      int n_items, int nqb, float scale, KvPages pg) {
+                      int n_items, int nqb, float scale, KvPages pg, const int32_t* __restrict__ cu) {
     typedef typename X16<E>::v8 bf16x8;   // (the names below were written for bf16; E may be _Float16)
     typedef typename X16<E>::v4 bf16x4;
     typedef E bf16_t;
@@ -1748,15 +1753,26 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     const int d_key = lane >> 3, d_ch = lane & 7;                 // this lane's slot inside an 8-key piece
     const unsigned dk_off = 2u * C + 16u * (d_ch ^ d_key);                              // K: chunk ^ (key & 7), key & 7 == d_key
     const unsigned dv_off = 4u * C + 16u * (d_ch ^ (((d_key >> 1) & 3) << 1));          // V: chunk ^ 2 ((key >> 1) & 3)
+    // PACKED ("varlen") INPUT, cu != NULL (round 4, DistilBERT on unpadded batches): the rows of sequence b are cu[b] .. cu[b + 1] - 1 of one
+    // [sum of lengths, 3 C] buffer, no padding rows and no key mask; every sequence fits one query block and one key stage (host check:
+    // max length <= KB, so nqb == nkb == 1 and an item is a (sequence, head)).  T then only sizes the grid; a sequence's own length
+    // bounds its key tiles, so a 20-token prompt computes one 64-key tile where the padded form computes the batch's maximum.
+    auto seq_rows = [&](int bb, int& row0, int& Tb) {            // wave-uniform (scalar loads)
+        if (cu) { row0 = cu[bb]; Tb = cu[bb + 1] - row0; } else { row0 = bb * T; Tb = T; }
+    };
+    struct ItemBase { const bf16_t* p; int Tb; };
     auto item_base = [&](int it) {                                // first qkv row of the item's (batch, head): wave-uniform, stays in SGPRs
         const int bh = it / nqb, bb = bh / H, hh = bh - bb * H;
-        return qkv + (int64_t)bb * T * 3 * C + hh * DH;
+        int row0, Tb;
+        seq_rows(bb, row0, Tb);
+        return ItemBase{qkv + (int64_t)row0 * 3 * C + hh * DH, Tb};
     };
-    auto issue_part = [&](const bf16_t* base, int kbi, int st, int i0, int i1) {   // pieces i0 .. i1 - 1 of this wave's four (K and V of 8 keys each)
+    auto issue_part = [&](const ItemBase& ib, int kbi, int st, int i0, int i1) {   // pieces i0 .. i1 - 1 of this wave's four (K and V of 8 keys each)
+        const bf16_t* base = ib.p;
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int piece = wave * 4 + i, key = piece * 8 + d_key;
-            int kr = kbi * KB + key; kr = kr < T ? kr : T - 1;
+            int kr = kbi * KB + key; kr = kr < ib.Tb ? kr : ib.Tb - 1;
             const unsigned row = (unsigned)kr * (unsigned)(6 * C);    // bytes; a sequence's rows span < 4 GB (checked on the host)
             const unsigned dst = lds_base + (unsigned)(st * STAGE + piece * 64) * 16u;
             glds16_hidden_s(base, row + dk_off, dst);
@@ -1767,19 +1783,23 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     auto mask_of = [&](int it, int kbi) -> int {                  // validity of key kbi * KB + tid (the first KB / 64 waves)
         const int bh = it / nqb, bb = bh / H;
         const int kidx = kbi * KB + tid;
-        int ok = (tid < KB && kidx < T) ? 1 : 0;
-        if (ok && mask) ok = mask[(int64_t)bb * T + kidx];
+        int row0, Tb;
+        seq_rows(bb, row0, Tb);
+        int ok = (tid < KB && kidx < Tb) ? 1 : 0;
+        if (ok && mask) ok = mask[(int64_t)bb * T + kidx];        // (packed input has no mask: host check)
         return ok;
     };
     bf16x8 qn[2][2];                                              // next item's raw Q fragments
     auto load_q = [&](int it) {
         const int bh = it / nqb, qb = it - bh * nqb, bb = bh / H, hh = bh - bb * H;
+        int row0, Tb;
+        seq_rows(bb, row0, Tb);
 #pragma unroll
         for (int mq = 0; mq < 2; ++mq) {
-            int qr = qb * QPB + wave * 32 + mq * 16 + c; qr = qr < T ? qr : T - 1;
+            int qr = qb * QPB + wave * 32 + mq * 16 + c; qr = qr < Tb ? qr : Tb - 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                qn[mq][ks] = *reinterpret_cast<const bf16x8*>(qkv + ((int64_t)bb * T + qr) * 3 * C + hh * DH + ks * 32 + 8 * g);
+                qn[mq][ks] = *reinterpret_cast<const bf16x8*>(qkv + ((int64_t)row0 + qr) * 3 * C + hh * DH + ks * 32 + 8 * g);
         }
     };
     // transposed-read offsets (bf16 elements) of this lane inside a 16-key group of the V image, one per 16-d block:
@@ -1796,13 +1816,13 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
     // its latency behind -- 2-3 us per item.
     float4 ov0, ov1, ov2, ov3;                                    // (scalars, not an array: an array captured by a lambda went to scratch)
     bf16_t* optr = nullptr;                                       // row of ov0; ov<i> is 8 i rows further; nullptr: nothing held
-    int orow = 0;                                                 // query index of ov0 within the sequence
+    int orow = 0, oT = 0;                                         // query index of ov0 within the sequence, and that sequence's length
 #define MGEA_FLUSH_OUT()                                                                               \
     if (optr) {                                                                                        \
-        if (orow < T)      *reinterpret_cast<float4*>(optr) = ov0;                                     \
-        if (orow + 8 < T)  *reinterpret_cast<float4*>(optr + (int64_t)8 * C) = ov1;                    \
-        if (orow + 16 < T) *reinterpret_cast<float4*>(optr + (int64_t)16 * C) = ov2;                   \
-        if (orow + 24 < T) *reinterpret_cast<float4*>(optr + (int64_t)24 * C) = ov3;                   \
+        if (orow < oT)      *reinterpret_cast<float4*>(optr) = ov0;                                    \
+        if (orow + 8 < oT)  *reinterpret_cast<float4*>(optr + (int64_t)8 * C) = ov1;                   \
+        if (orow + 16 < oT) *reinterpret_cast<float4*>(optr + (int64_t)16 * C) = ov2;                  \
+        if (orow + 24 < oT) *reinterpret_cast<float4*>(optr + (int64_t)24 * C) = ov3;                  \
     }
     int item = blockIdx.x, kb = 0, stage = 0, mk = 0;
     if (item < n_items) { issue(item, 0, 0); mk = mask_of(item, 0); load_q(item); }
@@ -1823,6 +1843,8 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
         // believes pending makes it wait (by ITS count, which does not include the hidden DMAs: in effect vmcnt(0)) before those
         // registers are written again -- right after the next unit's DMA was issued, which would serialise the pipeline.
         asm volatile("" : "+v"(qn[0][0]), "+v"(qn[0][1]), "+v"(qn[1][0]), "+v"(qn[1][1]), "+v"(mk));
+        int row0cur, Tcur;                                        // the current item's sequence: first row, length
+        seq_rows((item / nqb) / H, row0cur, Tcur);
         if (tid < KB) {
             const unsigned long long bal = __ballot(mk != 0);
             if (lane == 0) sValid[stage * VW + wave] = bal;
@@ -1855,7 +1877,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                     const int tok0 = kb * KB + wave * 32;                                   // 32-aligned: one page
                     const unsigned long long vw = sValid[stage * VW + (wave >> 1)];
                     const unsigned vbits = (unsigned)(vw >> (32 * (wave & 1)));             // validity of this wave's 32 keys
-                    if (tok0 < T && (tok0 >> 6) < pg.max_pages) {
+                    if (tok0 < Tcur && (tok0 >> 6) < pg.max_pages) {
                         const int phys = pg.page_table[bb * pg.max_pages + (tok0 >> 6)];
                         const int64_t pe = pg.pool.page_elems();
                         _Float16* kpage = static_cast<_Float16*>(pg.pool.base) + pg.layer * pg.pool.layer_stride + ((int64_t)(phys * 2) * H + hh) * pe;
@@ -1889,8 +1911,8 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
         if (nkbi == nkb) { nitem = item + gridDim.x; nkbi = 0; }
         // PIPE, full stage: the next unit's 8 LDS-DMA pieces are issued inside the tile loop below, a quarter per tile, instead of as a
         // burst here (stamps, round 3: 0.85 us per unit during which all 8 waves only issue and the matrix pipe idles)
-        const bool dma_in_loop = PIPE && NW == 8 && (kb + 1) * KB <= T;
-        const bf16_t* nbase = item_base(nitem < n_items ? nitem : item);   // (two integer divisions: once per unit, not once per piece)
+        const bool dma_in_loop = PIPE && NW == 8 && (kb + 1) * KB <= Tcur;
+        const ItemBase nbase = item_base(nitem < n_items ? nitem : item);   // (two integer divisions: once per unit, not once per piece)
         if (nitem < n_items) {                                    // the other stage was last read before the barrier above
             if (!dma_in_loop) issue(nitem, nkbi, stage ^ 1);
             mk = mask_of(nitem, nkbi);
@@ -1994,7 +2016,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 oacc[1][dt] = X16<E>::mfma(u.v, pf[1][p], oacc[1][dt]);
             }
         };
-        if (PIPE && (kb + 1) * KB <= T) {
+        if (PIPE && (kb + 1) * KB <= Tcur) {
             // SOFTWARE-PIPELINED form for a full stage (round 4).  In the rolled loop below a tile is Q K^T (16 MFMAs), then ~190 vector
             // instructions of softmax, then P V (20 MFMAs): matrix pipe and vector ALU take turns -- 576 + ~770 cycles per wave and
             // tile, and the two waves of a SIMD, which run the same program between the same barriers, do it in lockstep (2,600 cycles
@@ -2018,7 +2040,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
             }
         } else {
 #pragma unroll 1
-            for (int t0 = 0; t0 < KB && kb * KB + t0 < T; t0 += 64) {   // workgroup-uniform bounds
+            for (int t0 = 0; t0 < KB && kb * KB + t0 < Tcur; t0 += 64) {   // workgroup-uniform bounds (packed input: this sequence's length)
                 f32x4 sc[2][4];                                   // both query blocks side by side: two independent dependency chains per wave
                 bf16x8 pf[2][2];                                  // [query block][32-key half]
                 qk_tile(t0, sc);
@@ -2060,7 +2082,8 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
                 ov3 = *reinterpret_cast<const float4*>(sp + 24 * 64);
             }
             orow = qb * QPB + wave * 32 + (lane >> 3);
-            optr = out + ((int64_t)bb * T + orow) * C + hh * DH + (lane & 7) * 8;
+            oT = Tcur;
+            optr = out + ((int64_t)row0cur + orow) * C + hh * DH + (lane & 7) * 8;
         }
         item = nitem; kb = nkbi; stage ^= 1;
         PH_STAMP(un * 8 + 5);
@@ -2071,7 +2094,7 @@ void attn_bf16_kernel(const E* __restrict__ qkv, const int32_t* __restrict__ mas
 }
 
 template <typename E, int NW, int PIPE>
-static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, hipStream_t st, const KvPages& pg) {
+static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, hipStream_t st, const KvPages& pg, const int32_t* cu) {
     constexpr int QPB = 32 * NW, KB = 32 * NW;
     const int nqb = ceil_div(T, QPB);
     const int64_t n_items = (int64_t)B * H * nqb;
@@ -2084,18 +2107,23 @@ static int launch_attn16(const void* qkv, const int32_t* mask, void* out, int B,
     const int per_cu = NW == 4 ? 2 : 1;
     const int grid = (int)(n_items < per_cu * di.n_cu ? n_items : per_cu * di.n_cu);
     hipLaunchKernelGGL((attn_bf16_kernel<E, NW, PIPE>), dim3(grid), dim3(64 * NW), shmem, st, (const E*)qkv, mask, (E*)out, T, H, (int)n_items, nqb,
-                       0.125f, pg);
+                       0.125f, pg, cu);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
 
-int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16, const KvPages* pages) {
+int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16, const KvPages* pages,
+                     const int32_t* cu) {
     MGEA_REQUIRE(dh == 64, MGEA_EINVAL, "bf16 attention: head_dim %d not supported (64)", dh);
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "bf16 attention: bad shape");
     MGEA_REQUIRE((int64_t)T * 6 * H * dh < ((int64_t)1 << 32), MGEA_EINVAL, "bf16 attention: one sequence of qkv rows must span < 4 GB");
     // long sequences: 256 queries / 256 keys per unit (switch attn16_wide: 0 never, 1 from 512 tokens (default), 2 always)
     const int wide = tune(TUNE_ATTN16_WIDE);
-    const bool w8 = wide == 2 || (wide == 1 && T >= 512);
+    bool w8 = wide == 2 || (wide == 1 && T >= 512);
+    if (cu) {   // packed input: T = the longest sequence, which must fit one query block / key stage of the form that runs it
+        MGEA_REQUIRE(!mask && T <= 256, MGEA_EINVAL, "16-bit attention over packed rows: no key mask, sequences of at most 256 tokens (got %d)", T);
+        w8 = T > 128;
+    }
     // the wide form runs its full stages software-pipelined (round 4; switch attn16_pipe = 0: the rolled tile loop).  The 4-wave form keeps
     // the rolled loop: at 128 keys it is memory-bound and the pipelined body spilled 31 registers (44 -> 54 us on [256, 128, 12 x 64])
     const bool pipe = tune(TUNE_ATTN16_PIPE) != 0;
@@ -2103,12 +2131,12 @@ int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int
     const KvPages none{};
     const KvPages& pg = pages ? *pages : none;
     if (f16) {
-        if (w8) return pipe ? launch_attn16<_Float16, 8, 1>(qkv, mask, out, B, T, H, st, pg) : launch_attn16<_Float16, 8, 0>(qkv, mask, out, B, T, H, st, pg);
-        return launch_attn16<_Float16, 4, 0>(qkv, mask, out, B, T, H, st, pg);
+        if (w8) return pipe ? launch_attn16<_Float16, 8, 1>(qkv, mask, out, B, T, H, st, pg, cu) : launch_attn16<_Float16, 8, 0>(qkv, mask, out, B, T, H, st, pg, cu);
+        return launch_attn16<_Float16, 4, 0>(qkv, mask, out, B, T, H, st, pg, cu);
     }
     MGEA_REQUIRE(!pg.pool.base, MGEA_EINVAL, "16-bit attention: KV pages are written by the fp16 instantiation only");
-    if (w8) return pipe ? launch_attn16<bf16_t, 8, 1>(qkv, mask, out, B, T, H, st, pg) : launch_attn16<bf16_t, 8, 0>(qkv, mask, out, B, T, H, st, pg);
-    return launch_attn16<bf16_t, 4, 0>(qkv, mask, out, B, T, H, st, pg);
+    if (w8) return pipe ? launch_attn16<bf16_t, 8, 1>(qkv, mask, out, B, T, H, st, pg, cu) : launch_attn16<bf16_t, 8, 0>(qkv, mask, out, B, T, H, st, pg, cu);
+    return launch_attn16<bf16_t, 4, 0>(qkv, mask, out, B, T, H, st, pg, cu);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -196,7 +196,8 @@ struct StepState {
     __host__ __device__ int eos() const { return params ? params->eos_id : eos_id; }
 };
 // one query per sequence (the [CLS] position, fp32 q [B, D]) against the K | V columns of a packed qkv buffer [B * S, 3 D] (fp32 or bf16) -> fp32 [B, D]
-int launch_attn_cls(const float* q, const void* qkv, int qkv_bf16, const int32_t* mask, float* out, int B, int S, int H, int dh, hipStream_t st);
+int launch_attn_cls(const float* q, const void* qkv, int qkv_bf16, const int32_t* mask, float* out, int B, int S, int H, int dh, hipStream_t st,
+                    const int32_t* cu = nullptr);
 int launch_logits_argmax(const float* P, int S, int64_t ps, int ldp, const float* bias, float* logits,
                          int M, int V, int32_t* argmax_out, hipStream_t st);
 // sampler over logits [B,V] (top_k != 1); writes ids[b]; probs_out optional
@@ -250,17 +251,19 @@ bool gemm_bf16_is_persistent(int M, int N, int K);
 int launch_ln_rowstat(const float* part, float* rowstat, int M, int n_part, int C, float eps, hipStream_t st);
 int launch_fold_ln_weights_bf16(const float* W, const float* gamma, const float* beta, const float* b, void* Wf, float* c1, float* c2,
                                 int N, int K, hipStream_t st, int f16 = 0);
+// cu (here and below; NULL = padded [B, S] rows): packed input, the rows of sequence b are cu[b] .. cu[b + 1] - 1
 int launch_gather_cls_ln_bf16(const void* h, const float* rowstat, const float* g, const float* be, float* out, int B, int S, int D,
-                              hipStream_t st);
+                              hipStream_t st, const int32_t* cu = nullptr);
 int launch_layernorm_bf16(const void* x, const float* w, const float* b, void* y, int M, int C, float eps, hipStream_t st);
 int launch_bert_embed_ln_bf16(const int32_t* ids, const float* word, const float* pos, const float* lnw, const float* lnb,
-                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag = nullptr);
-int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st);
+                              float eps, void* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag = nullptr,
+                              const int32_t* pos_ids = nullptr);
+int launch_gather_cls_bf16(const void* h, float* out, int B, int S, int D, hipStream_t st, const int32_t* cu = nullptr);
 // pages (fp16 instantiation only, or NULL): the K | V rows of every key whose mask bit is set also go to the fp16 KV pages of `layer` at
 // position t (decoder prefill into an empty cache: the attention kernel has those rows in LDS anyway)
 struct KvPages { KvPool pool; int layer; const int32_t* page_table; int max_pages; };
 int launch_attn_bf16(const void* qkv, const int32_t* mask, void* out, int B, int T, int H, int dh, hipStream_t st, int f16 = 0,
-                     const KvPages* pages = nullptr);
+                     const KvPages* pages = nullptr, const int32_t* cu = nullptr);
 
 // fp16 big-batch prefill of the decoder (bf16.hip): embedding rows as fp16 + their (mean, rstd); K | V of fp16 qkv rows -> fp16 KV pages
 int launch_dec_embed_f16(const int32_t* ids, const int32_t* lens, const int32_t* ctx_len, const float* tok_emb, const float* pos_emb,

@@ -30,7 +30,8 @@ def _logits(text: Union[str, Sequence[str]]) -> torch.Tensor:
     if model is None:
         configure()
     inputs = tokenizer(text, return_tensors="pt", truncation=True, padding=True)     # inference.py:16
-    logits, _ = model.forward(inputs["input_ids"], inputs["attention_mask"], want_argmax=False)
+    # (a batch of texts runs on packed rows where the engine can: a bf16 engine, >= 512 real tokens -- same logits, no padding rows computed)
+    logits, _ = model.forward_auto(inputs["input_ids"], inputs["attention_mask"], want_argmax=False)
     return logits.cpu()
 
 

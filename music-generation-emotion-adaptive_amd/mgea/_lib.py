@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mgea_bert_create": (C.c_int, [C.POINTER(BertConfig), _P, C.POINTER(_P)]),
     "mgea_bert_destroy": (C.c_int, [_P]),
     "mgea_bert_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
+    "mgea_bert_forward_packed": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "mgea_bert_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "mgea_lora_merge": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "mgea_op_gemm_workspace_floats": (_I64, [_I32, _I32, _I32]),

@@ -208,7 +208,52 @@ class BertEngine:
         check(self.lib.mgea_bert_stats(self.h, out))
         return dict(forwards=out[0], folded_layernorm=bool(out[1]), gemm_persistent=out[2], gemm_ring=out[3], gemm_small=out[4],
                     gemm_half_tile_tails=out[5], layernorm_kernels=out[6], last_layer_cls_only=bool(out[7]),
-                    gemm_by_epilogue=[int(out[8 + e]) for e in range(6)])
+                    gemm_by_epilogue=[int(out[8 + e]) for e in range(6)], rows=int(out[14]))
+
+    PACKED_MIN_TOKENS = 512      # the 16-bit kernels' routing threshold (csrc/bert.hip: BF16_MIN_TOKENS)
+    PACKED_MAX_LEN = 256         # one query block / key stage of the 16-bit flash attention per sequence
+
+    @staticmethod
+    def pack(ids: torch.Tensor, mask: Optional[torch.Tensor]):
+        """HOST tensors [B, S] + 0/1 mask -> (ids [n] int32, pos [n] int32, cu_seqlens [B + 1] int32, max_len) of the real tokens, or None
+        when the mask is not a prefix mask (holes / leading padding: only the padded form represents those) or a sequence is empty.
+        The tokenizer of emotion_analysis/inference.py:16 (padding=True) pads on the right, so its masks are prefix masks."""
+        B, S = ids.shape
+        if mask is None:
+            return None
+        m = mask.to(torch.bool)
+        lens = m.sum(1)
+        if int(lens.min()) < 1 or not bool((m == (torch.arange(S)[None, :] < lens[:, None])).all()):
+            return None
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = lens.cumsum(0).to(torch.int32)
+        pos = torch.arange(S, dtype=torch.int32)[None, :].expand(B, S)[m].contiguous()
+        return ids[m].to(torch.int32).contiguous(), pos, cu, int(lens.max())
+
+    def forward_packed(self, ids: torch.Tensor, pos: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, want_logits=True, want_argmax=True):
+        """The forward on PACKED rows (pack() above; mgea_bert_forward_packed): ids / pos [n_tokens], cu_seqlens [B + 1], max_len <= 256.
+        Same (logits [B, labels], argmax [B]) as forward() on the padded batch."""
+        B = int(cu_seqlens.numel()) - 1
+        n = int(ids.numel())
+        if not ids.is_cuda and n and (int(ids.min()) < 0 or int(ids.max()) >= self.geo["vocab"]):
+            raise IndexError("index out of range in self")
+        ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        pos32 = pos.to(device=self.device, dtype=torch.int32).contiguous()
+        cu32 = cu_seqlens.to(device=self.device, dtype=torch.int32).contiguous()
+        logits = torch.empty(B, self.num_labels, dtype=torch.float32, device=self.device) if want_logits else None
+        amax = torch.empty(B, dtype=torch.int32, device=self.device) if want_argmax else None
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.mgea_bert_forward_packed(self.h, ptr(ids32), ptr(pos32), ptr(cu32), B, n, int(max_len), ptr(logits), ptr(amax), st))
+        return logits, amax
+
+    def forward_auto(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, want_logits=True, want_argmax=True):
+        """forward(), on packed rows where that applies: a bf16 engine, HOST ids / mask as the tokenizer produces them, a right-padded
+        batch of at least 512 real tokens whose longest sequence has at most 256 -- otherwise the padded call."""
+        if self.dtype == "bf16" and not ids.is_cuda and mask is not None and not mask.is_cuda and ids.dim() == 2:
+            pk = self.pack(ids, mask)
+            if pk is not None and pk[0].numel() >= self.PACKED_MIN_TOKENS and pk[3] <= self.PACKED_MAX_LEN and pk[0].numel() < ids.numel():
+                return self.forward_packed(*pk, want_logits=want_logits, want_argmax=want_argmax)
+        return self.forward(ids, mask, want_logits, want_argmax)
 
     def id_errors(self, raise_error: bool = True) -> int:
         """Read and clear the engine's sticky device flags (ONE stream sync): bit 0 = some token id handed over as a DEVICE tensor
