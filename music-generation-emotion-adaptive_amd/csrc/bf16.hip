@@ -1375,8 +1375,9 @@ static int pick_bf16_kernel(int M, int N, int K, int ldc) {
     if (!(M >= 512 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && K % 64 == 0) || tune(TUNE_BF16_GEMM_SMALL)) return 0;
     const int force = tune(TUNE_BF16_GEMM_TILE);
     const int64_t blocks256 = (int64_t)ceil_div(M, 256) * ceil_div(N, 256);
-    // 256-wide N tiles unless that leaves too few workgroups for 256 CUs
-    return (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 256)) ? 2 : 1;
+    // 256-wide N tiles unless that leaves too few workgroups for 256 CUs.  (From 192 tiles on, round 4: the packed DistilBERT batch -- 18.8 k
+    // real tokens of [256, 128] -- is 74 x 3 = 222 tiles at N = 768, and only the persistent kernel has the folded-LayerNorm epilogues.)
+    return (force == 4 || (force == 0 && N % 256 == 0 && blocks256 >= 192)) ? 2 : 1;
 }
 
 template <int EPI>

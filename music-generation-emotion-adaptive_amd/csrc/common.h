@@ -365,7 +365,8 @@ __device__ __forceinline__ void kv_store4(const KvPool& pool, int layer, int phy
     }
 }
 
-// End of a decode step for row b, by one 256-thread workgroup whose thread 0 holds the new token `tok`:
+// End of a decode step for row b, by one workgroup of >= 256 threads whose thread 0 holds the new token `tok` (threads >= 256 only take part
+// in the barriers: the sampler's workgroup has 1024):
 // the sampler-loop bookkeeping of api_cache.py:179-181 (append, EOS stop) and the NEXT step's embedding
 // x[b] = tok_emb[fed] + pos_emb[pos] (k-tiled) with its LayerNorm statistics (two equal half-row partials).
 // st_* = the row's state as loaded by thread 0 at kernel start.  sh: >= 6 floats of shared scratch.
@@ -403,7 +404,7 @@ __device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::Ta
     for (int i = 0; i < 4; ++i) {
         const int f = tid + i * 256;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < nf4) {
+        if (f < nf4 && tid < 256) {
             v[i] = add4(ld4(t.tok_emb + (int64_t)id * C + f * 4), ld4(t.pos_emb + (int64_t)pos * C + f * 4));
             st4(t.x + mgea::tiled_off(b, f * 4, C), v[i]);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -412,7 +413,7 @@ __device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::Ta
     auto bsum = [&](float val) {
         val = wave_sum(val);
         __syncthreads();
-        if (lane == 0) sh[wave] = val;
+        if (lane == 0 && wave < 4) sh[wave] = val;
         __syncthreads();
         return (sh[0] + sh[1]) + (sh[2] + sh[3]);
     };
@@ -421,7 +422,7 @@ __device__ __forceinline__ void advance_embed_row(int b, int tok, const mgea::Ta
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + i * 256;
-        if (f < nf4) {
+        if (f < nf4 && tid < 256) {
             const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
             q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }

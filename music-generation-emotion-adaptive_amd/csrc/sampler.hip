@@ -2,7 +2,11 @@
 //   logits / temperature -> additive -1e10 outside the top-k -> softmax -> multinomial(1)
 // plus a build-defined nucleus (top-p) cut that the reference does not have.
 //
-// One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted:
+// One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted.  (Round 4 tried
+// 1024 threads per row: 21.9 / 32.3 us for top-k / top-p at B = 64, V = 8324 against 20 / 31.9 -- the passes of the bisection are bound by
+// what ONE CU issues per pass and by its barrier, not by the registers a thread carries.  What a top-k pass did cost was its counting: a
+// ballot + s_bcnt1 per logit goes through the CU's single scalar unit, 8 k scalar instructions per row; per-lane counters and one DPP
+// reduction per pass keep it on the vector ALUs.)
 //   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys held in
 //             registers (integer counts -> deterministic); kept = {logit > k-th} plus as many of the
 //             entries EQUAL to the k-th as it takes to keep exactly k, lowest ids first (topk + scatter_ of
@@ -41,12 +45,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
     }
 }
 
-__device__ __forceinline__ float block_sum_f(float v, float* red) {
+constexpr int SAMP_NT = 256, SAMP_NW = SAMP_NT / 64;   // threads / waves per row
+
+__device__ __forceinline__ float block_sum_f(float v, float* red /* [SAMP_NW] */) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SAMP_NW; ++w) t += red[w];          // fixed order: deterministic
+    return t;
 }
 
 // xor-butterfly sum over each aligned group of 16 lanes with DPP (a few cycles per step), then across the four groups
@@ -70,7 +79,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // bytes its 64-bit LDS atomics serialised.)
 template <bool MASS, int MAXE>
 __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE], const uint32_t (&whi)[MAXE], const uint32_t (&wlo)[MAXE],
-                                                    uint32_t floor_key, unsigned long long target, unsigned long long* red /* [8] */,
+                                                    uint32_t floor_key, unsigned long long target, unsigned long long* red /* [2 * SAMP_NW] */,
                                                     unsigned long long* weight_at_boundary = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t prefix = 0u;
@@ -89,15 +98,17 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
             }
             mine = ((unsigned long long)wave_sum_u32(hi) << 20) + wave_sum_u32(lo);
         } else {
-            uint32_t cnt = 0u;
+            uint32_t cnt = 0u;                                  // per-lane count, ONE wave reduction per pass (header comment)
 #pragma unroll
-            for (int j = 0; j < MAXE; ++j) cnt += (uint32_t)__popcll(__ballot(key[j] >= lim));
-            mine = cnt;
+            for (int j = 0; j < MAXE; ++j) cnt += key[j] >= lim ? 1u : 0u;
+            mine = wave_sum_u32(cnt);
         }
-        unsigned long long* slot = red + 4 * (bit & 1);
+        unsigned long long* slot = red + SAMP_NW * (bit & 1);
         if (lane == 0) slot[wave] = mine;
         __syncthreads();
-        const unsigned long long tot = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int w = 0; w < SAMP_NW; ++w) tot += slot[w];
         if (tot >= target) { prefix = cand; at = tot; }
     }
     __syncthreads();   // the slots are reused by the caller
@@ -105,22 +116,23 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
     return prefix > floor_key ? prefix : floor_key;
 }
 
-// One 256-thread workgroup per row; thread t owns the logits t, t + 256, ... in registers (MAXE of them), so the row is
+// One SAMP_NT-thread workgroup per row; thread t owns the logits t, t + SAMP_NT, ... in registers (MAXE of them), so the row is
 // read from memory once, in one batch of loads, and never goes through LDS.
 template <int MAXE>
-__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int V, SamplerParams pv,
+__global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict__ logits, int V, SamplerParams pv,
                                                     const SamplerParams* __restrict__ pd,
                                                     const int32_t* __restrict__ row_step, int64_t step_host,
                                                     int32_t* __restrict__ ids_out, float* __restrict__ probs_out,
                                                     TailArgs tail, int fuse_tail) {
-    __shared__ unsigned long long red64[8];
-    __shared__ int s_tie[4];
+    constexpr int NT = SAMP_NT, NW = SAMP_NW;
+    __shared__ unsigned long long red64[2 * NW];
+    __shared__ int s_tie[NW];
     if (pd) pv = *pd;   // device-resident scalars (one 32-byte scalar load) win over the by-value copy
     const float temperature = pv.temperature, top_p = pv.top_p;
     const int top_k = pv.top_k;
     const uint64_t seed = ((uint64_t)pv.seed_hi << 32) | pv.seed_lo;
-    __shared__ float redf[4];
-    __shared__ float s_scan[4];
+    __shared__ float redf[NW];
+    __shared__ float s_scan[NW];
     __shared__ int s_thread, s_choice;
     __shared__ float sh_tail[8];
 
@@ -130,12 +142,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (fuse_tail && tid == 0) {
         st_step = tail.s.row_step[b]; st_fed = tail.s.cur_ids[b]; st_len = tail.s.ctx_len[b]; st_done = tail.s.done[b];
     }
-    // the whole row is requested at once (a rolled loop pays one ~1 us round trip per 256 logits: the row was just
+    // the whole row is requested at once (a rolled loop pays one ~1 us round trip per pass: the row was just
     // written by the head kernel and sits in another XCD's L2 / the Infinity Cache)
     float x[MAXE];
 #pragma unroll
     for (int j = 0; j < MAXE; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + NT * j;
         x[j] = i < V ? lg[i] : -INFINITY;
     }
     float mx = -INFINITY;
@@ -148,12 +160,14 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     mx = wave_max(mx);
     if ((tid & 63) == 0) redf[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    mx = redf[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, redf[w]);
 
     uint32_t key[MAXE], whi[MAXE], wlo[MAXE];
 #pragma unroll
     for (int j = 0; j < MAXE; ++j) {
-        key[j] = (tid + 256 * j < V) ? fkey(x[j]) : 0u;   // 0 = below every candidate
+        key[j] = (tid + NT * j < V) ? fkey(x[j]) : 0u;   // 0 = below every candidate
         whi[j] = wlo[j] = 0u;
     }
     uint32_t keep_key = 0u;  // keep everything
@@ -162,13 +176,16 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64, &n_ge);
         if (n_ge > (unsigned long long)top_k) {
             // several logits equal the k-th largest: keep exactly top_k entries, the tied ones by ascending id
-            // (id = tid + 256 j, so the order is j-major, thread-minor).  Rare (exact fp32 ties): block-uniform branch.
+            // (id = tid + NT j, so the order is j-major, thread-minor).  Rare (exact fp32 ties): block-uniform branch.
             uint32_t n_gt = 0u;
 #pragma unroll
             for (int j = 0; j < MAXE; ++j) n_gt += (uint32_t)__popcll(__ballot(key[j] > keep_key));
             if ((tid & 63) == 0) s_tie[tid >> 6] = (int)n_gt;
             __syncthreads();
-            const int need = top_k - ((s_tie[0] + s_tie[1]) + (s_tie[2] + s_tie[3]));   // >= 1 tied entries survive
+            int n_gt_all = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) n_gt_all += s_tie[w];
+            const int need = top_k - n_gt_all;   // >= 1 tied entries survive
             __syncthreads();
             int seen = 0;   // tied entries with a lower id than this pass's (block-uniform)
 #pragma unroll
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 if ((tid & 63) == 0) s_tie[tid >> 6] = __popcll(bal);
                 __syncthreads();
                 int before = seen + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < NW; ++w) {
                     if (w < (tid >> 6)) before += s_tie[w];
                     seen += s_tie[w];
                 }
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
     }
 
-    // ---- final distribution over the kept set; CDF order = thread-major (t, then t + 256, ...): any fixed order gives
+    // ---- final distribution over the kept set; CDF order = thread-major (t, then t + NT, ...): any fixed order gives
     // the same distribution
     float e[MAXE];
     float loc = 0.f;
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         e[j] = (key[j] != 0u && key[j] >= keep_key) ? __expf(x[j] - mx) : 0.f;
         loc += e[j];
     }
-    // exclusive prefix of the per-thread masses in thread order: a fixed tree (wave scan, then the four wave totals left
+    // exclusive prefix of the per-thread masses in thread order: a fixed tree (wave scan, then the wave totals left
     // to right) -> deterministic
     float inc = loc;
 #pragma unroll
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     __syncthreads();
     float wpre = 0.f, total = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if (w == (tid >> 6)) wpre = total;
         total += s_scan[w];
     }
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const float inv = 1.0f / total;
 #pragma unroll
         for (int j = 0; j < MAXE; ++j)
-            if (tid + 256 * j < V) probs_out[(int64_t)b * V + tid + 256 * j] = e[j] * inv;
+            if (tid + NT * j < V) probs_out[(int64_t)b * V + tid + NT * j] = e[j] * inv;
     }
     if (!ids_out) return;
     uint32_t ctr[4] = {(uint32_t)b, (uint32_t)(row_step ? row_step[b] : (int32_t)step_host),
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             }
         }
         const int jj = pick >= 0 ? pick : last;
-        s_choice = jj >= 0 ? tid + 256 * jj : -1;
+        s_choice = jj >= 0 ? tid + NT * jj : -1;
     }
     __syncthreads();
     const int tok = s_choice >= 0 ? s_choice : 0;
@@ -273,11 +290,12 @@ int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& 
     MGEA_REQUIRE(!tail || (ids_out && tail->C % 4 == 0 && tail->C <= 4096), MGEA_EINVAL, "sampler: bad fused-tail arguments");
     const TailArgs t = tail ? *tail : TailArgs{};
     const SamplerParams pv = sampler_params(s);
-    if (V <= 256 * 36)
-        hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(256), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
+    static_assert(SAMP_NT * 56 >= MGEA_SAMPLER_MAX_VOCAB, "the register-resident row must hold the largest vocabulary");
+    if (V <= SAMP_NT * 36)
+        hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(SAMP_NT), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
                            probs_out, t, tail ? 1 : 0);
     else
-        hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(256), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
+        hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(SAMP_NT), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
                            probs_out, t, tail ? 1 : 0);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
