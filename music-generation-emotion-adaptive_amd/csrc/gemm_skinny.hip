@@ -402,7 +402,20 @@ static int launch_skinny_mt(const SkinnyArgs& a_in, int nw, hipStream_t st) {
     // compile-time chunk counts for the decode shapes (8 waves x NCH chunks of 32): K = 512 (NCH 2), 768 (3), 2048 (8); anything
     // else, other wave counts and the timestamp mode of tools/skinny_phases.py take the generic stream (NCH 0)
     const int nch = (nw == 8 && !(a.dbg & (1 << 20)) && a.K % 256 == 0) ? a.K / 256 : 0;
-#define MGEA_SKINNY_GO(LNV, NTV, F16V, NCHV) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, LNV, MT, NTV, F16V, NCHV>), grid, block, shmem, st, a)
+    // switch skinny_one_per_cu (A/B, round 4): pad the dynamic LDS request beyond half a CU's 160 KB so that no two workgroups of a launch with
+    // <= 256 workgroups can share a CU (the head kernel of head_gemm.hip relies on the same effect)
+    const bool one_per_cu = tune(TUNE_SKINNY_ONE_PER_CU) && grid.x * grid.y <= 256;
+    const size_t shmem_go = one_per_cu && shmem < 84 * 1024 ? 84 * 1024 : shmem;
+#define MGEA_SKINNY_GO(LNV, NTV, F16V, NCHV)                                                                                              \
+    do {                                                                                                                                 \
+        if (one_per_cu) {                                                                                                                \
+            static uint64_t attr_done = 0;                                                                                               \
+            DeviceInfo di;                                                                                                               \
+            MGEA_TRY(device_info(&di));                                                                                                  \
+            MGEA_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, LNV, MT, NTV, F16V, NCHV>), 84 * 1024, di.dev, &attr_done)); \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, LNV, MT, NTV, F16V, NCHV>), grid, block, shmem_go, st, a);                           \
+    } while (0)
 #define MGEA_SKINNY_NCH(LNV, NTV, F16V)                                                                  \
     do {                                                                                                 \
         if (nch == 2) MGEA_SKINNY_GO(LNV, NTV, F16V, 2);                                                  \
