@@ -2,11 +2,11 @@
 //   logits / temperature -> additive -1e10 outside the top-k -> softmax -> multinomial(1)
 // plus a build-defined nucleus (top-p) cut that the reference does not have.
 //
-// One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted.  (Round 4 tried
-// 1024 threads per row: 21.9 / 32.3 us for top-k / top-p at B = 64, V = 8324 against 20 / 31.9 -- the passes of the bisection are bound by
-// what ONE CU issues per pass and by its barrier, not by the registers a thread carries.  What a top-k pass did cost was its counting: a
-// ballot + s_bcnt1 per logit goes through the CU's single scalar unit, 8 k scalar instructions per row; per-lane counters and one DPP
-// reduction per pass keep it on the vector ALUs.)
+// One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted.  (Round 4 measured
+// two ways of spending more hardware on a row, both NEUTRAL: 1024 threads per row -- 21.9 / 32.3 us for top-k / top-p at B = 64, V = 8324
+// against 20 / 31.9 -- and per-lane counters with one DPP reduction per pass instead of a ballot + s_bcnt1 per logit -- 22.8 us.  A pass of
+// the bisection costs ~0.4 us whatever a thread carries: it is one count -> LDS -> barrier -> LDS round trip, 32 of them in a row; fewer
+// passes, not wider ones, is what would shorten it -- profiles/README.md.)
 //   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys held in
 //             registers (integer counts -> deterministic); kept = {logit > k-th} plus as many of the
 //             entries EQUAL to the k-th as it takes to keep exactly k, lowest ids first (topk + scatter_ of
@@ -98,10 +98,10 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
             }
             mine = ((unsigned long long)wave_sum_u32(hi) << 20) + wave_sum_u32(lo);
         } else {
-            uint32_t cnt = 0u;                                  // per-lane count, ONE wave reduction per pass (header comment)
+            uint32_t cnt = 0u;
 #pragma unroll
-            for (int j = 0; j < MAXE; ++j) cnt += key[j] >= lim ? 1u : 0u;
-            mine = wave_sum_u32(cnt);
+            for (int j = 0; j < MAXE; ++j) cnt += (uint32_t)__popcll(__ballot(key[j] >= lim));
+            mine = cnt;
         }
         unsigned long long* slot = red + SAMP_NW * (bit & 1);
         if (lane == 0) slot[wave] = mine;
