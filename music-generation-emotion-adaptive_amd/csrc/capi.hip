@@ -222,7 +222,8 @@ int mgea_op_skinny(int32_t epi, const float* a_dev, const float* w_dev, const fl
     MGEA_REQUIRE(epi == EPI_ACT || epi == EPI_RES || epi == EPI_LOGITS, MGEA_EINVAL, "op_skinny: epilogue %d not exposed", epi);
     if (epi == EPI_LOGITS) {   // LM head: logits [M,N] row-major in out_dev (or NULL); per-tile (max, argmax) partials in stats_out_dev
         MGEA_REQUIRE(stats_out_dev, MGEA_EINVAL, "op_skinny: the LOGITS epilogue writes its partials to stats_out_dev");
-        const int tiles = skinny_logits_tiles(M, N, K);
+        // (tools that pass ablation / timestamp bits in dbg run the generic kernel, whose partial count differs from the balanced head kernel's)
+        const int tiles = (dbg & ~(1 << 21)) ? skinny_logits_tiles(M, N, 0) : skinny_logits_tiles(M, N, K);
         a.pmax_val = stats_out_dev;
         a.pmax_idx = reinterpret_cast<int32_t*>(stats_out_dev + (int64_t)64 * tiles);
     }

@@ -471,8 +471,8 @@ static int launch_skinny_t(const SkinnyArgs& a, hipStream_t st) {
 }
 
 // number of per-row partial (max, argmax) entries the LOGITS epilogue writes = its grid.x
-int skinny_logits_tiles(int M, int N, int K) {
-    const int g = head_balanced_partials(M, N, K);
+int skinny_logits_tiles(int M, int N, int K) {   // K = 0: the generic kernel's count whatever the shape
+    const int g = K > 0 ? head_balanced_partials(M, N, K) : 0;
     if (g) return g;
     return (M > 32 && N >= 4096) ? ceil_div(N, 32) : ceil_div(N, 16);
 }
