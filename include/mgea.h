@@ -193,13 +193,15 @@ int mgea_bert_destroy(mgea_bert* h);
  * bert_full_last_layer = 1 computes every position). */
 int mgea_bert_forward(mgea_bert* h, const int32_t* ids_dev, const int32_t* mask_dev, int32_t B,
                       int32_t S, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
-/* PACKED forward (bf16 engines): the real tokens of the B sequences back to back instead of [B, S] rows padded to the batch's longest
+/* PACKED forward: the real tokens of the B sequences back to back instead of [B, S] rows padded to the batch's longest
  * prompt (what the tokenizer call of emotion_analysis/inference.py:16 -- padding=True -- hands to the model).  ids_dev / pos_ids_dev
  * [n_tokens] int32 (token id; position of the token inside its sequence), cu_seqlens_dev [B + 1] int32 (sequence b = rows cu[b] ..
- * cu[b + 1] - 1; cu[0] = 0, cu[B] = n_tokens), max_len = the longest sequence (<= 256).  Every row-wise GEMM, LayerNorm statistic
+ * cu[b + 1] - 1; cu[0] = 0, cu[B] = n_tokens), max_len = the longest sequence.  Every row-wise GEMM, LayerNorm statistic
  * and attention tile then runs on real tokens only; same logits as the padded call with the corresponding prefix mask (a row's results
- * do not depend on the other rows of the batch, and a sequence attends to exactly its own keys in both forms).  Needs at least 512
- * tokens (the 16-bit kernels' routing threshold): smaller calls belong to mgea_bert_forward. */
+ * do not depend on the other rows of the batch, and a sequence attends to exactly its own keys in both forms).  Both engine modes take it:
+ * F32 engines (and BF16 engines below their 512-token routing threshold) on the exact-fp32 kernels with sequences of any length up to
+ * max_pos, BF16 engines from 512 tokens on with sequences of at most 256 tokens.  The caller guarantees a consistent cu_seqlens
+ * (non-decreasing, cu[B] = n_tokens, cu[b + 1] - cu[b] in 1..max_len): it is device memory and is not read back. */
 int mgea_bert_forward_packed(mgea_bert* h, const int32_t* ids_dev, const int32_t* pos_ids_dev, const int32_t* cu_seqlens_dev, int32_t B,
                              int32_t n_tokens, int32_t max_len, float* logits_out_dev, int32_t* argmax_out_dev, void* stream);
 /* Token ids handed over as DEVICE memory are not read back before the forward (that would put a host sync in front of every call):

@@ -20,7 +20,7 @@ namespace mgea {
 template <int DH>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lens,
                                                         const int32_t* __restrict__ mask, float* __restrict__ out,
-                                                        int T, int H, float scale, int tiled_out) {
+                                                        int T_pad, int H, float scale, int tiled_out, const int32_t* __restrict__ cu) {
     constexpr int NCH = DH / 4;   // 16-B chunks per row
     constexpr int DC = DH / 16;   // 16-wide d tiles
     constexpr int F4 = 64 * NCH / 256;
@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict
     const int q0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)b * T;
+    // packed rows (cu != NULL, DistilBERT on unpadded batches): sequence b = rows cu[b] .. cu[b + 1] - 1, all real; the grid is sized
+    // for the longest sequence, blocks past this one's end leave at once and its key loop stops at its own length
+    const int64_t row0 = cu ? (int64_t)cu[b] : (int64_t)b * T_pad;
+    const int T = cu ? cu[b + 1] - cu[b] : T_pad;
+    if (q0 >= T) return;
     const int nvalid = lens ? lens[b] : T;
 
     // Q fragments (pre-scaled): query q0 + wave*16 + c, d = dc*16 + 4g .. +3
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict
         if (tid < 64) {
             const int kidx = k0 + tid;
             bool ok = kidx < T && kidx < nvalid;
-            if (ok && mask) ok = mask[row0 + kidx] != 0;
+            if (ok && mask) ok = mask[row0 + kidx] != 0;   // (padded rows only: row0 = b * T_pad)
             sValid[tid] = ok ? 1 : 0;
         }
         __syncthreads();
@@ -150,14 +154,15 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const float* __restrict
 }
 
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T, int H,
-                      int dh, int tiled_out, hipStream_t st) {
+                      int dh, int tiled_out, hipStream_t st, const int32_t* cu) {
+    MGEA_REQUIRE(!(cu && (lens || mask || tiled_out)), MGEA_EINVAL, "attention: packed rows carry no lengths / mask");
     MGEA_REQUIRE(B > 0 && T > 0 && B <= 65535 && H <= 65535, MGEA_EINVAL, "attention: bad shape B=%d T=%d H=%d", B, T, H);
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(ceil_div(T, 64), H, B);
     switch (dh) {
-        case 32: hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
-        case 64: hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
-        case 96: hipLaunchKernelGGL(attn_dense_kernel<96>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out); break;
+        case 32: hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out, cu); break;
+        case 64: hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out, cu); break;
+        case 96: hipLaunchKernelGGL(attn_dense_kernel<96>, grid, dim3(256), 0, st, qkv, lens, mask, out, T, H, scale, tiled_out, cu); break;
         default:
             MGEA_REQUIRE(false, MGEA_EINVAL, "attention: head_dim %d not supported (32, 64, 96)", dh);
     }

@@ -205,10 +205,12 @@ static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t
     MGEA_REQUIRE(S <= c.max_pos, MGEA_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, c.max_pos);
     MGEA_REQUIRE(M64 > 0 && M64 <= c.max_tokens, MGEA_ECAPACITY, "%lld tokens exceed max_tokens %d", (long long)M64, c.max_tokens);
     const int M = (int)M64, D = c.dim, Hd = c.hidden, NL = c.num_labels, dh = D / c.n_heads;
-    if (cu)
-        MGEA_REQUIRE(c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS && !mask_dev && pos_ids && S <= 256 && dh == 64, MGEA_EINVAL,
-                     "bert_forward_packed: needs a bf16 engine, at least %d tokens, sequences of at most 256 tokens (got %d tokens, longest %d)",
-                     BF16_MIN_TOKENS, M, S);
+    if (cu) {
+        MGEA_REQUIRE(!mask_dev && pos_ids && M >= B, MGEA_EINVAL, "bert_forward_packed: packed rows carry positions, no mask, and at least one token per sequence");
+        // the 16-bit attention takes a sequence as ONE query block / key stage (<= 256 tokens); the exact-fp32 kernels take any length
+        MGEA_REQUIRE(!(c.dtype == MGEA_DTYPE_BF16 && M >= BF16_MIN_TOKENS) || S <= 256, MGEA_EINVAL,
+                     "bert_forward_packed on the 16-bit kernels: sequences of at most 256 tokens (longest here: %d)", S);
+    }
     auto gemm = [&](const float* A, int lda, const float* W, int m, int n, int k, int* Sout) -> int {
         const int s = pick_split_k(m, n, k, h->slab_cap);
         MGEA_REQUIRE((int64_t)s * slab_floats(m, n) <= h->slab_cap, MGEA_ECAPACITY, "internal: bert slab workspace too small");
@@ -347,8 +349,10 @@ static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t
         }
     } else {
     h->last_cls_only = cls_last ? 1 : 0;
-    MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
-                                  D, c.vocab, st, h->err_flag));
+    if (cu) MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, M, 1, D, c.vocab, st,
+                                          h->err_flag, pos_ids));
+    else MGEA_TRY(launch_bert_embed_ln(ids_dev, h->w(B_WORD), h->w(B_POS), h->w(B_ELNW), h->w(B_ELNB), c.ln_eps, h->h, B, S,
+                                       D, c.vocab, st, h->err_flag));
     for (int l = 0; l < c.n_layers; ++l) {
         if (cls_last && l == last) {               // K | V of every position (columns D.. of the stacked projection), the rest on the [CLS] rows
             const float *wkv = h->lw(l, BL_QKVW) + (int64_t)D * D, *bkv = h->lw(l, BL_QKVB) + D;
@@ -358,7 +362,7 @@ static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t
                 MGEA_TRY(gemm(h->h, D, wkv, M, 2 * D, D, &Sk));
                 MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 2 * D), (int)slab_ld(2 * D), bkv, h->qkv + D, 3 * D, M, 2 * D, ACT_NONE, st));
             }
-            MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+            MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st, cu));
             MGEA_TRY(cls_tail(l, h->qkv, 0));
             break;
         }
@@ -370,7 +374,7 @@ static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t
             MGEA_TRY(launch_bias_act(h->slabs, Sk, slab_floats(M, 3 * D), (int)slab_ld(3 * D), h->lw(l, BL_QKVB), h->qkv,
                                      3 * D, M, 3 * D, ACT_NONE, st));
         }
-        MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, 0, st));
+        MGEA_TRY(launch_attn_dense(h->qkv, nullptr, mask_dev, h->ctx, B, S, c.n_heads, dh, 0, st, cu));
         MGEA_TRY(gemm(h->ctx, D, h->lw(l, BL_OUTW), M, D, D, &Sk));
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_OUTB), h->h, nullptr,
                                     h->lw(l, BL_SALNW), h->lw(l, BL_SALNB), c.ln_eps, M, D, 1, st));
@@ -385,7 +389,7 @@ static int bert_forward_impl(mgea_bert* h, const int32_t* ids_dev, const int32_t
         MGEA_TRY(launch_bias_res_ln(h->slabs, Sk, slab_floats(M, D), (int)slab_ld(D), h->lw(l, BL_L2B), h->h, nullptr,
                                     h->lw(l, BL_OLNW), h->lw(l, BL_OLNB), c.ln_eps, M, D, 1, st));
     }
-    if (!cls_last) MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st));
+    if (!cls_last) MGEA_TRY(launch_gather_rows(h->h, D, h->pooled, D, B, S, D, st, cu));
     }
     // pooled = h[:, 0]  ->  pre_classifier -> ReLU -> classifier (fp32 in both modes)
     MGEA_TRY(gemm(h->pooled, D, h->hw(0), B, D, D, &Sk));

@@ -154,7 +154,7 @@ int launch_embed_ln(const int32_t* ids, const int32_t* lens, const int32_t* ctx_
 // BERT embedding: h[m] = LN(word[ids[m]] + pos[t])
 int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
                          const float* lnb, float eps, float* h, int B, int S, int D, int vocab,
-                         hipStream_t st, int32_t* err_flag = nullptr);
+                         hipStream_t st, int32_t* err_flag = nullptr, const int32_t* pos_ids = nullptr);   // pos_ids: packed rows (B = rows, S = 1)
 // qkv epilogue of the decoder: v = sum P + bias over [M, 3C]; q -> qbuf[m, C] (and k|v -> kvbuf
 // [m, 2C] if kvbuf != NULL, for the no-cache attention); k, v of real tokens -> KV pages of `layer`
 // at position ctx_len[b] + t.
@@ -168,7 +168,7 @@ int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int
                       int C, int tiled_out, hipStream_t st);
 // dense non-causal attention over the qkv buffer itself (prefill without past, BERT)
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T,
-                      int H, int dh, int tiled_out, hipStream_t st);
+                      int H, int dh, int tiled_out, hipStream_t st, const int32_t* cu = nullptr);   // cu: packed rows (T = the longest sequence)
 
 // The sampler's scalars as the kernels read them from DEVICE memory (one 32-byte record per engine): a captured
 // decode-step graph holds only the pointer, so one graph serves every request whatever its seed / temperature /
@@ -222,7 +222,7 @@ int launch_add_lens(int32_t* ctx_len, const int32_t* lens, int T, int B, hipStre
 // cur_ids[b] = ids[b, (lens ? lens[b] : T) - 1]
 int launch_take_last(const int32_t* ids, const int32_t* lens, int32_t* cur_ids, int B, int T, hipStream_t st);
 int launch_gather_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int row_step, int C,
-                       hipStream_t st);
+                       hipStream_t st, const int32_t* row_idx = nullptr);   // row_idx: source row of output row r (instead of r * row_step)
 int launch_lora_merge(float* w, const float* a, const float* b, int out_dim, int in_dim, int r, float scale,
                       hipStream_t st);
 

@@ -146,10 +146,10 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __res
                                                            const float* __restrict__ pos, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, float eps,
                                                            float* __restrict__ h, int S, int D, int vocab,
-                                                           int32_t* __restrict__ err_flag) {
+                                                           int32_t* __restrict__ err_flag, const int32_t* __restrict__ pos_ids) {
     __shared__ float red[4];
     const int64_t m = blockIdx.x;
-    const int t = (int)(m % S);
+    const int t = pos_ids ? pos_ids[m] : (int)(m % S);          // packed rows carry their position
     const int nf4 = D >> 2;
     int id = ids[m];
     // an id outside the vocabulary (nn.Embedding raises IndexError) is clamped and reported through the engine's sticky flag
@@ -170,10 +170,11 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __res
 }
 
 int launch_bert_embed_ln(const int32_t* ids, const float* word, const float* pos, const float* lnw,
-                         const float* lnb, float eps, float* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag) {
+                         const float* lnb, float eps, float* h, int B, int S, int D, int vocab, hipStream_t st, int32_t* err_flag,
+                         const int32_t* pos_ids) {
     MGEA_REQUIRE(D % 4 == 0 && D <= 4096, MGEA_EINVAL, "bert embed: dim=%d must be a multiple of 4 and <= 4096", D);
     hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(B * S), dim3(256), 0, st, ids, word, pos, lnw, lnb, eps, h, S, D,
-                       vocab, err_flag);
+                       vocab, err_flag, pos_ids);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }
@@ -405,14 +406,15 @@ int launch_take_last(const int32_t* ids, const int32_t* lens, int32_t* cur_ids, 
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
-                                   int row_step, int C) {
+                                   int row_step, int C, const int32_t* __restrict__ row_idx) {
     const int64_t r = blockIdx.x;
+    const int64_t sr = row_idx ? (int64_t)row_idx[r] : r * row_step;
     for (int f = threadIdx.x; f < (C >> 2); f += blockDim.x)
-        st4(dst + r * ld_dst + f * 4, ld4(src + r * row_step * (int64_t)ld_src + f * 4));
+        st4(dst + r * ld_dst + f * 4, ld4(src + sr * (int64_t)ld_src + f * 4));
 }
 int launch_gather_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int row_step, int C,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, st, src, ld_src, dst, ld_dst, row_step, C);
+                       hipStream_t st, const int32_t* row_idx) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, st, src, ld_src, dst, ld_dst, row_step, C, row_idx);
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

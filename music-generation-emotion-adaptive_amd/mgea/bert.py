@@ -210,8 +210,8 @@ class BertEngine:
                     gemm_half_tile_tails=out[5], layernorm_kernels=out[6], last_layer_cls_only=bool(out[7]),
                     gemm_by_epilogue=[int(out[8 + e]) for e in range(6)], rows=int(out[14]))
 
-    PACKED_MIN_TOKENS = 512      # the 16-bit kernels' routing threshold (csrc/bert.hip: BF16_MIN_TOKENS)
-    PACKED_MAX_LEN = 256         # one query block / key stage of the 16-bit flash attention per sequence
+    BF16_MIN_TOKENS = 512        # a bf16 engine's routing threshold (csrc/bert.hip): smaller calls run on its exact-fp32 kernels
+    PACKED_MAX_LEN_16BIT = 256   # one query block / key stage of the 16-bit flash attention per sequence
 
     @staticmethod
     def pack(ids: torch.Tensor, mask: Optional[torch.Tensor]):
@@ -231,7 +231,8 @@ class BertEngine:
         return ids[m].to(torch.int32).contiguous(), pos, cu, int(lens.max())
 
     def forward_packed(self, ids: torch.Tensor, pos: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, want_logits=True, want_argmax=True):
-        """The forward on PACKED rows (pack() above; mgea_bert_forward_packed): ids / pos [n_tokens], cu_seqlens [B + 1], max_len <= 256.
+        """The forward on PACKED rows (pack() above; mgea_bert_forward_packed): ids / pos [n_tokens], cu_seqlens [B + 1], max_len = the longest
+        sequence (any length on the exact-fp32 kernels; <= 256 on a bf16 engine's 16-bit kernels, i.e. from 512 tokens on).
         Same (logits [B, labels], argmax [B]) as forward() on the padded batch."""
         B = int(cu_seqlens.numel()) - 1
         n = int(ids.numel())
@@ -247,12 +248,14 @@ class BertEngine:
         return logits, amax
 
     def forward_auto(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, want_logits=True, want_argmax=True):
-        """forward(), on packed rows where that applies: a bf16 engine, HOST ids / mask as the tokenizer produces them, a right-padded
-        batch of at least 512 real tokens whose longest sequence has at most 256 -- otherwise the padded call."""
-        if self.dtype == "bf16" and not ids.is_cuda and mask is not None and not mask.is_cuda and ids.dim() == 2:
+        """forward(), on packed rows where that applies: HOST ids / mask as the tokenizer produces them, a right-padded batch with at
+        least one padding token (and, on a bf16 engine's 16-bit kernels, no sequence longer than 256) -- otherwise the padded call."""
+        if not ids.is_cuda and mask is not None and not mask.is_cuda and ids.dim() == 2:
             pk = self.pack(ids, mask)
-            if pk is not None and pk[0].numel() >= self.PACKED_MIN_TOKENS and pk[3] <= self.PACKED_MAX_LEN and pk[0].numel() < ids.numel():
-                return self.forward_packed(*pk, want_logits=want_logits, want_argmax=want_argmax)
+            if pk is not None and pk[0].numel() < ids.numel():
+                on16 = self.dtype == "bf16" and pk[0].numel() >= self.BF16_MIN_TOKENS
+                if not on16 or pk[3] <= self.PACKED_MAX_LEN_16BIT:
+                    return self.forward_packed(*pk, want_logits=want_logits, want_argmax=want_argmax)
         return self.forward(ids, mask, want_logits, want_argmax)
 
     def id_errors(self, raise_error: bool = True) -> int:

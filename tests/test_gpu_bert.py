@@ -104,3 +104,37 @@ def test_device_resident_ids_outside_the_vocabulary_are_reported(dtype, tune):
     eng.forward(bad.cuda())
     assert eng.id_errors(raise_error=False) == 1
     eng.close()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "base"])
+def test_packed_forward_of_the_f32_engine_vs_golden_and_padded(golden, tag):
+    """The PACKED forward (mgea_bert_forward_packed) on the parity engine: the golden fixture's ragged rows, given as real tokens back to
+    back, against the transformers-generated golden logits (1e-4, labels exact) and against the padded call of the same engine
+    (fp32 summation noise: the attention cuts a sequence's keys into the same 64-key tiles in both forms, the GEMMs cut the rows into
+    different 128-row tiles of identical per-element arithmetic -> observed exactly equal).  Both forms of the last layer."""
+    from mgea import _lib
+    from mgea.bert import BertEngine
+    g = golden("distilbert_" + tag)
+    seed, vocab, max_pos, dim, n_heads, n_layers, hidden, gb, seq = (int(x) for x in g["cfg"])
+    sd = synth.distilbert_state_dict(seed, vocab, max_pos, dim, n_layers, hidden)
+    ad = synth.lora_adapter(seed, dim, n_layers)
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    eng = BertEngine(sd, n_heads=n_heads, adapter=ad, max_tokens=gb * seq, dtype="f32")
+    for full_last in (0, 1):
+        old = _lib.tune_set("bert_full_last_layer", full_last)
+        try:
+            padded, _ = eng.forward(ids, mask)
+            pk = BertEngine.pack(ids, mask)
+            assert pk is not None and pk[0].numel() == int(mask.sum()) < ids.numel()
+            logits, amax = eng.forward_packed(*pk)
+            assert eng.stats()["rows"] == int(mask.sum())
+            auto, _ = eng.forward_auto(ids, mask)
+            assert eng.stats()["rows"] == int(mask.sum()) and torch.equal(auto, logits)
+        finally:
+            _lib.tune_set("bert_full_last_layer", old)
+        d_gold = np.abs(logits.cpu().numpy() - g["logits"]).max()
+        d_pad = float((logits - padded).abs().max())
+        print(f"[f32 packed {tag}, full_last={full_last}] vs golden {d_gold:.2e}, vs padded {d_pad:.2e}")
+        assert d_gold < 1e-4 and d_pad < 2e-5
+        assert amax.cpu().tolist() == g["argmax"].tolist()
+    eng.close()

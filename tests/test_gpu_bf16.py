@@ -595,9 +595,15 @@ def test_bert_bf16_packed_forward_short_and_ragged_batches(tune):
         d = float((got - want).abs().max())
         print(f"[bf16 packed] B={B} longest {S}, {int(lens.sum())} tokens: max |packed - padded| = {d:.2e}")
         assert d < 5e-3
-    with pytest.raises(RuntimeError):                                # fewer than 512 tokens: not the packed path's business
-        small = torch.ones(4, 8, dtype=torch.long)
-        eng.forward_packed(*BertEngine.pack(small, torch.ones_like(small)))
+    # fewer than 512 tokens: the bf16 engine's exact-fp32 kernels, which take packed rows too (any sequence length)
+    lens = np.array([300, 1, 17, 64, 65])
+    S = 300
+    ids = torch.from_numpy(rs.randint(1, 3000, size=(5, S))).long()
+    mask = (torch.arange(S)[None, :] < torch.from_numpy(lens)[:, None]).long()
+    want, _ = eng.forward(ids * mask, mask)
+    got, _ = eng.forward_packed(*BertEngine.pack(ids * mask, mask))
+    assert eng.stats()["rows"] == int(lens.sum()) and eng.stats()["gemm_persistent"] == 0
+    assert float((got - want).abs().max()) < 2e-5
     eng.close()
 
 
