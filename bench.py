@@ -163,7 +163,7 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None, r
                                                  frac=flops_all / dt_all / 1e12 / peak, traffic=None),
                                    note="switch bert_full_last_layer = 1: every position of the last layer computed and all but one per sequence "
                                         "discarded, as the reference does; the figure of rounds 1-2"))
-    if dtype == "bf16":
+    if True:
         # PACKED rows (round 4): the real tokens of the batch back to back -- the tokenizer pads to the longest prompt (inference.py:16), 44 % of
         # this batch is padding.  Reported BESIDE the padded figures (the padded every-position number stays the roofline evidence); FLOPs counted
         # are those executed on the real tokens.  The packed ids / positions / offsets are the input format (resident before the clock starts),
@@ -174,7 +174,7 @@ def bert_extra(device, steps, warmup, with_cpu, dtype="f32", sd=None, ad=None, r
         lg_pk = eng.forward_packed(*pk_dev)[0]
         rows = eng.stats()["rows"]
         d_pk = float((lg_pk - lg_pad).abs().max())
-        assert rows == int(mask.sum()) and d_pk < 5e-3, f"packed DistilBERT forward differs from the padded one by {d_pk}"
+        assert rows == int(mask.sum()) and d_pk < (5e-3 if dtype == "bf16" else 1e-4), f"packed DistilBERT forward differs from the padded one by {d_pk}"
         for _ in range(max(1, warmup)):
             eng.forward_packed(*pk_dev)
         torch.cuda.synchronize()
