@@ -15,12 +15,13 @@ eng = DecoderEngine(sd, n_head=8, max_batch=B, max_ctx=T, dtype="f16")
 ids = torch.from_numpy(synth.integers(1, "p", (B, T), 0, 8324)).cuda()
 old = _lib.tune_get(name)
 res = {}
+WL = os.environ.get("PREFILL_LOGITS", "0") == "1"      # PREFILL_LOGITS=1: with the logits of every position (the head GEMM, 2.2 GB of fp32 rows)
 for rep in range(5):
     for v in vals:
         _lib.tune_set(name, v)
-        for _ in range(2): eng.reset_and_prefill(ids, want_logits=False)
+        for _ in range(2): eng.reset_and_prefill(ids, want_logits=WL)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5): eng.reset_and_prefill(ids, want_logits=False)
+        for _ in range(5): eng.reset_and_prefill(ids, want_logits=WL)
         torch.cuda.synchronize(); res.setdefault(v, []).append((time.perf_counter() - t0) / 5 * 1e3)
 _lib.tune_set(name, old)
 flops = 2 * B * T * (6 * 12 * 512 * 512) + 4 * B * T * T * 512 * 6
