@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_FILES = ("r3_pmc_fetch_size_attn.json", "r2_pmc_fetch_size_full.json", "r1_v6_pmc_fetch_size_full.json")   # newest committed FETCH_SIZE pass first
+PMC_FILES = ("r4_pmc_fetch_size_attn.json", "r3_pmc_fetch_size_attn.json", "r2_pmc_fetch_size_full.json", "r1_v6_pmc_fetch_size_full.json")   # newest committed FETCH_SIZE pass first
 
 DEC = dict(vocab=8324, seq_len=1024, d_model=512, n_layer=6, d_ff=2048)   # train/train_large2.py:10-12,23-28
 N_HEAD = 8                                                                 # api_cache.py:112
@@ -507,7 +507,7 @@ def main():
             # duration, without the ~2.5 us of dispatch that an event pair around a single launch includes (all 1019 x 6 launches of a
             # generation there, every 16th step here: the same mean context)
             trace = None
-            kst = os.path.join(ROOT, "profiles", "r3_bench_kernel_stats.csv")
+            kst = os.path.join(ROOT, "profiles", "r4_bench_kernel_stats.csv")
             if os.path.exists(kst):
                 import csv
                 for r in csv.DictReader(open(kst)):
@@ -515,7 +515,7 @@ def main():
                         t_us = float(r["AverageNs"]) / 1e3
                         alg = B * N_HEAD * 2 * (Tp + (n_steps - 1) / 2 + 1) * dh * 4     # mean over all steps of the generation
                         trace = dict(avg_launch_us=t_us, launches=int(r["Calls"]), achieved=alg / (t_us * 1e-6) / 1e9,
-                                     frac=alg / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, source="profiles/r3_bench_kernel_stats.csv (committed pass, not this run)")
+                                     frac=alg / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, source="profiles/r4_bench_kernel_stats.csv (committed pass, not this run)")
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, kernel_trace=trace,
                         traffic=traffic, traffic_source=traffic_source, kernel="attn_paged_kernel<64>", launches=a["launches"],
                         avg_launch_us=a["ms"] * 1e3 / a["launches"],
