@@ -56,6 +56,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_HEAD_BALANCED,        // 1 (default): the LM head of a 3..64-row decode step on head_balanced_kernel (one workgroup per CU, equal unit counts); 0: the generic skinny kernel
        TUNE_ATTN16_PIPE,          // 1 (default): the 16-bit flash attention runs full key stages software-pipelined (next tile's Q K^T under this tile's exponentials); 0: rolled loop
        TUNE_SKINNY_ONE_PER_CU,    // 1: skinny GEMM launches of <= 256 workgroups ask for > 80 KB of LDS, so that no two share a CU (A/B; default 0)
+       TUNE_SAMPLER_WAVE_SELECT,  // 1 (default): top_k <= 64 finds its boundary wave by wave (ballots only) and merges 4 x 64 candidates after one barrier; 0: block-wide bisection, a barrier per bit
        TUNE_COUNT };
 int tune(int key);
 

@@ -4,11 +4,10 @@
 //
 // One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted.  (Round 4 measured
 // two ways of spending more hardware on a row, both NEUTRAL: 1024 threads per row -- 21.9 / 32.3 us for top-k / top-p at B = 64, V = 8324
-// against 20 / 31.9 -- and per-lane counters with one DPP reduction per pass instead of a ballot + s_bcnt1 per logit -- 22.8 us.  A pass of
-// the bisection costs ~0.4 us whatever a thread carries: it is one count -> LDS -> barrier -> LDS round trip, 32 of them in a row; fewer
-// passes, not wider ones, is what would shorten it -- profiles/README.md.)
-//   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys held in
-//             registers (integer counts -> deterministic); kept = {logit > k-th} plus as many of the
+// against 20 / 31.9 -- and per-lane counters with one DPP reduction per pass instead of a ballot + s_bcnt1 per logit -- 22.8 us.  What did
+// pay is taking the row out of the passes: "top-k without a pass over the row per bit" below, 21.0 -> 11.5 us.)
+//   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys (integer counts ->
+//             deterministic), over a pivot-selected candidate list for top_k <= 64, over the registers otherwise; kept = {logit > k-th} plus as many of the
 //             entries EQUAL to the k-th as it takes to keep exactly k, lowest ids first (topk + scatter_ of
 //             api_cache.py:172-175 keeps exactly top_k entries; which of several tied ones torch keeps is
 //             unspecified, lowest-id is this build's rule).  exp(-1e10) underflows to exactly 0 in fp32, so
@@ -116,6 +115,78 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
     return prefix > floor_key ? prefix : floor_key;
 }
 
+// ---- top-k without a pass over the row per bit (round 4).  A wave issues one instruction per ~5 cycles when it is alone on its SIMD, as
+// here, scalar ones included: the block-wide bisection is 32 x (36 compares + 72 scalar count instructions), ~12 us of the kernel's 21.
+// (A first attempt kept those passes and only dropped their barrier -- every wave bisecting its own quarter, candidates merged at the end:
+// 25 us, SLOWER; the passes themselves are the cost.)  Instead a PIVOT cuts the row down to a few dozen candidates first:
+//   1. every lane takes the largest of its keys; every wave bisects ITS 64 lane maxima (one compare per pass) for the j-th largest,
+//      j = ceil(k / 4); the pivot P is the smallest of the four.  At least 4 j >= k logits are >= P, so the k-th largest is >= P, and with
+//      one logit in ~36 being a lane maximum the number of logits >= P is about k (k = 50: 60-70 of 8324);
+//   2. one pass over the row writes the keys >= P into the wave's 64 LDS slots (ballot prefix; most ballots are empty);
+//   3. after a barrier every wave bisects the <= 4 x 64 candidates (4 per lane) for the k-th largest of the row, and counts the
+//      candidates at or above it -- that is every such logit of the row, so ties are seen exactly as before.
+// A wave with more than 64 logits >= P (heavy ties, or fewer than j valid lanes in some wave) sends the block to the block-wide
+// bisection.  Integer counts throughout: same boundary key either way.  top_k <= SAMP_KFAST takes this path.
+constexpr int SAMP_KFAST = 64;
+
+template <int N>
+__device__ __forceinline__ uint32_t wave_kth_largest(const uint32_t (&key)[N], uint32_t k) {   // 0 when fewer than k keys are non-zero
+    uint32_t prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int j = 0; j < N; ++j) cnt += (uint32_t)__popcll(__ballot(key[j] >= cand));
+        if (cnt >= k) prefix = cand;
+    }
+    return prefix;
+}
+
+// keys >= pivot (> 0) of this wave's registers -> slots[0, 64), zeros behind them; returns how many there were (may exceed 64)
+template <int N>
+__device__ __forceinline__ int wave_publish_ge(const uint32_t (&key)[N], uint32_t pivot, uint32_t* slots) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool up = key[j] >= pivot;
+        const unsigned long long m = __ballot(up);
+        if (m != 0ull) {   // wave-uniform, rarely taken
+            const int pos = base + __popcll(m & below);
+            if (up && pos < SAMP_KFAST) slots[pos] = key[j];
+            base += __popcll(m);
+        }
+    }
+    if (lane >= base) slots[lane] = 0u;   // SAMP_KFAST == 64: one lane per slot
+    return base;
+}
+
+// the mass bisection of bisect_boundary<true> over candidates a single wave holds (R per lane): same integers, same boundary
+template <int R>
+__device__ __forceinline__ uint32_t wave_mass_boundary(const uint32_t (&key)[R], const uint32_t (&whi)[R], const uint32_t (&wlo)[R],
+                                                       uint32_t floor_key, unsigned long long target) {
+    uint32_t prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        const uint32_t lim = cand > floor_key ? cand : floor_key;
+        uint32_t hi = 0u, lo = 0u;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const bool in = key[j] >= lim;
+            hi += in ? whi[j] : 0u;
+            lo += in ? wlo[j] : 0u;
+        }
+        const unsigned long long tot = ((unsigned long long)wave_sum_u32(hi) << 20) + wave_sum_u32(lo);
+        if (tot >= target) prefix = cand;
+    }
+    return prefix > floor_key ? prefix : floor_key;
+}
+
+__device__ __forceinline__ float funkey(uint32_t k) {   // inverse of fkey
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 // One SAMP_NT-thread workgroup per row; thread t owns the logits t, t + SAMP_NT, ... in registers (MAXE of them), so the row is
 // read from memory once, in one batch of loads, and never goes through LDS.
 template <int MAXE>
@@ -123,10 +194,12 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
                                                     const SamplerParams* __restrict__ pd,
                                                     const int32_t* __restrict__ row_step, int64_t step_host,
                                                     int32_t* __restrict__ ids_out, float* __restrict__ probs_out,
-                                                    TailArgs tail, int fuse_tail) {
+                                                    TailArgs tail, int fuse_tail, int wave_select) {
     constexpr int NT = SAMP_NT, NW = SAMP_NW;
+    static_assert(SAMP_KFAST == 64, "wave_publish_ge fills one slot per lane");
     __shared__ unsigned long long red64[2 * NW];
-    __shared__ int s_tie[NW];
+    __shared__ uint32_t s_cand[NW * SAMP_KFAST];
+    __shared__ int s_tie[NW], s_fit[NW];
     if (pd) pv = *pd;   // device-resident scalars (one 32-byte scalar load) win over the by-value copy
     const float temperature = pv.temperature, top_p = pv.top_p;
     const int top_k = pv.top_k;
@@ -171,9 +244,41 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
         whi[j] = wlo[j] = 0u;
     }
     uint32_t keep_key = 0u;  // keep everything
+    uint32_t cand[NW] = {};  // wave-select path: this lane's share of the candidates (all waves hold the same list)
+    bool cand_cover = false; // ... and they contain every entry >= keep_key (no ties beyond top_k)
     if (top_k > 0 && top_k < V) {
         unsigned long long n_ge = 0;
-        keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64, &n_ge);
+        bool fast = false;
+        if (wave_select && top_k <= SAMP_KFAST) {
+            uint32_t lm[1] = {key[0]};
+#pragma unroll
+            for (int j = 1; j < MAXE; ++j) lm[0] = lm[0] > key[j] ? lm[0] : key[j];
+            const uint32_t piv_w = wave_kth_largest<1>(lm, (uint32_t)((top_k + NW - 1) / NW));
+            if ((tid & 63) == 0) s_tie[tid >> 6] = (int)piv_w;
+            __syncthreads();
+            uint32_t pivot = (uint32_t)s_tie[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) pivot = pivot < (uint32_t)s_tie[w] ? pivot : (uint32_t)s_tie[w];
+            if (pivot != 0u) {   // block-uniform; 0: some wave has fewer than j valid lanes (a tiny vocabulary)
+                const int n_w = wave_publish_ge<MAXE>(key, pivot, s_cand + (tid >> 6) * SAMP_KFAST);
+                if ((tid & 63) == 0) s_fit[tid >> 6] = n_w;
+            }
+            __syncthreads();
+            fast = pivot != 0u;
+            if (fast) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) fast = fast && s_fit[w] <= SAMP_KFAST;
+            }
+            if (fast) {
+#pragma unroll
+                for (int r = 0; r < NW; ++r) cand[r] = s_cand[(tid & 63) + 64 * r];
+                keep_key = wave_kth_largest<NW>(cand, (uint32_t)top_k);   // >= pivot: at least top_k candidates exist
+#pragma unroll
+                for (int r = 0; r < NW; ++r) n_ge += (unsigned long long)__popcll(__ballot(cand[r] >= keep_key));
+                cand_cover = n_ge == (unsigned long long)top_k;   // more: ties, trimmed below in the registers only
+            }
+        }
+        if (!fast) keep_key = bisect_boundary<false, MAXE>(key, whi, wlo, 0u, (unsigned long long)top_k, red64, &n_ge);
         if (n_ge > (unsigned long long)top_k) {
             // several logits equal the k-th largest: keep exactly top_k entries, the tied ones by ascending id
             // (id = tid + NT j, so the order is j-major, thread-minor).  Rare (exact fp32 ties): block-uniform branch.
@@ -209,16 +314,32 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < MAXE; ++j) z += (key[j] != 0u && key[j] >= keep_key) ? __expf(x[j] - mx) : 0.f;
         const float invZ = 1.0f / block_sum_f(z, redf);
-#pragma unroll
-        for (int j = 0; j < MAXE; ++j) {
-            if (key[j] != 0u && key[j] >= keep_key) {
-                const unsigned long long w = (unsigned long long)((double)(__expf(x[j] - mx) * invZ) * 1099511627776.0);
-                whi[j] = (uint32_t)(w >> 20);   // <= 2^20: 64 lanes x MAXE of them stay below 2^32
-                wlo[j] = (uint32_t)(w & 0xFFFFFu);
-            }
-        }
         const unsigned long long target = (unsigned long long)((double)top_p * 1099511627776.0);
-        keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
+        if (cand_cover) {
+            // the kept set is among the candidates every wave already holds: the nucleus boundary without a barrier per bit.  The
+            // masses are the same integers (same x, mx, invZ), so the boundary is the one the block-wide bisection finds.
+            uint32_t chi[NW], clo[NW];
+#pragma unroll
+            for (int r = 0; r < NW; ++r) {
+                chi[r] = clo[r] = 0u;
+                if (cand[r] != 0u && cand[r] >= keep_key) {
+                    const unsigned long long w = (unsigned long long)((double)(__expf(funkey(cand[r]) - mx) * invZ) * 1099511627776.0);
+                    chi[r] = (uint32_t)(w >> 20);
+                    clo[r] = (uint32_t)(w & 0xFFFFFu);
+                }
+            }
+            keep_key = wave_mass_boundary<NW>(cand, chi, clo, keep_key, target);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) {
+                if (key[j] != 0u && key[j] >= keep_key) {
+                    const unsigned long long w = (unsigned long long)((double)(__expf(x[j] - mx) * invZ) * 1099511627776.0);
+                    whi[j] = (uint32_t)(w >> 20);   // <= 2^20: 64 lanes x MAXE of them stay below 2^32
+                    wlo[j] = (uint32_t)(w & 0xFFFFFu);
+                }
+            }
+            keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
+        }
     }
 
     // ---- final distribution over the kept set; CDF order = thread-major (t, then t + NT, ...): any fixed order gives
@@ -293,10 +414,10 @@ int launch_sample(const float* logits, int B, int V, const mgea_sampler_config& 
     static_assert(SAMP_NT * 56 >= MGEA_SAMPLER_MAX_VOCAB, "the register-resident row must hold the largest vocabulary");
     if (V <= SAMP_NT * 36)
         hipLaunchKernelGGL(sample_kernel<36>, dim3(B), dim3(SAMP_NT), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
-                           probs_out, t, tail ? 1 : 0);
+                           probs_out, t, tail ? 1 : 0, tune(TUNE_SAMPLER_WAVE_SELECT));
     else
         hipLaunchKernelGGL(sample_kernel<56>, dim3(B), dim3(SAMP_NT), 0, st, logits, V, pv, params_dev, row_step_dev, step_host, ids_out,
-                           probs_out, t, tail ? 1 : 0);
+                           probs_out, t, tail ? 1 : 0, tune(TUNE_SAMPLER_WAVE_SELECT));
     MGEA_CHECK_HIP(hipGetLastError());
     return MGEA_OK;
 }

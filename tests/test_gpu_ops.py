@@ -142,6 +142,39 @@ def test_topk_keeps_exactly_k_on_ties(ops):
     assert 1 <= int((probs > 0).sum()) <= k
 
 
+def test_topk_wave_by_wave_selection_equals_the_block_wide_bisection(ops, tune):
+    """Round 4: top_k <= 64 finds the boundary per wave on ballots and merges 4 x 64 candidates after one barrier (sampler.hip).  Integer
+    counts both ways, so ids and pre-draw probabilities must be IDENTICAL to the block-wide bisection (switch sampler_wave_select = 0):
+    random rows, rows with ties at and around the boundary, a vocabulary smaller than one wave's share, k = 1 + top-p, k = 64, and the
+    nucleus cut taken from the candidate list."""
+    g = torch.Generator().manual_seed(5)
+    rows = [torch.randn(5, 8324, generator=g) * 3, torch.randn(3, 700, generator=g), torch.randn(2, 40, generator=g),
+            torch.randn(2, 12000, generator=g)]
+    tie = torch.full((3, 8324), -2.0)
+    tie[0, 1000:1100] = 4.0                                  # 100 entries tied for the top: every k cuts inside the tie
+    tie[1, ::256] = 1.0; tie[1, 3] = 2.0                     # one wave's lanes hold all the large entries
+    tie[2] = torch.randn(8324, generator=g).round()          # few distinct values: ties everywhere
+    rows.append(tie)
+    rows.append(torch.cat([torch.full((1, 300), float("-inf")), torch.randn(1, 200, generator=g)], 1))   # -inf entries
+    for lg in rows:
+        V = lg.shape[1]
+        for k, pth, temp in [(1, 0.9, 1.0), (2, None, 1.0), (7, 0.3, 0.7), (50, None, 1.0), (50, 0.9, 1.3), (63, 0.5, 1.0), (64, None, 1.0),
+                             (64, 0.999, 1.0), (65, None, 1.0)]:
+            if k >= V:
+                continue
+            out = []
+            for sw in (0, 1):
+                tune("sampler_wave_select", sw)
+                ids, probs = ops.sample(lg.cuda(), temp, k, pth, seed=9, step=4, want_probs=True)
+                out.append((ids.cpu(), probs.cpu()))
+            assert torch.equal(out[0][0], out[1][0]), (V, k, pth)
+            assert torch.equal(out[0][1], out[1][1]), (V, k, pth)
+            kept = (out[1][1] > 0).sum(1)
+            assert bool((kept <= k).all()) and bool((kept >= 1).all())
+            if pth is None and bool(torch.isfinite(lg).all()):
+                assert bool((kept == k).all())
+
+
 def test_sampler_distribution(ops):
     """Distributional check of the multinomial draw (the reference's torch.multinomial stream
     cannot be reproduced; chi-square style bound on empirical frequencies)."""

@@ -49,6 +49,9 @@ for s in $STEPS; do
                f=$(find /tmp/pp_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prefill_${PREFILL_DTYPE:-f32}_kernel_stats.csv && python3 tools/kstats.py $f "" 14 ;;
     attn16ab)  run attn16ab 300 python3 tools/attn16_ab.py ${AB_SWITCH:-attn16_pipe} ${AB_VALUES:-0 1} || exit 1 ;;
     attntests) run attntests 600 python3 -m pytest tests/test_gpu_bf16.py tests/test_gpu_f16.py -x -q -m gpu -k "attention or prefill" || exit 1 ;;
+    sampler)   run samplertests 600 python3 -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "sampler or topk" || exit 1
+               MGEA_SAMPLER_WAVE_SELECT=0 run sampler_old 200 python3 tools/sampler_bench.py || exit 1
+               run sampler_new 200 python3 tools/sampler_bench.py || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
