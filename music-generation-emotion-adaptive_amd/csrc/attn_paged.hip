@@ -30,12 +30,22 @@ __device__ __forceinline__ float kv_elem(const f32x4& raw, int j) {
     return raw[j];
 }
 
-template <int DH, bool F16>
+// SPLIT (small batches, round 4): the pages of one (row, head, query) are spread over gridDim.z workgroups -- split z takes pages
+// 4z .. 4z+3, then 4 (z + gridDim.z) ..., one per wave -- and the workgroups that found pages leave an unnormalised (max, sum, acc[dh])
+// partial in `sp.part`; the one that arrives last at the (row, head, query)'s counter merges them in split order (deterministic) and
+// writes the output.  Nobody waits for anybody: no spinning, nothing to hang.  Partials and counter are written and read with
+// device-scope (sc1) stores, loads and atomics, so the protocol does not depend on which XCD (which L2) a workgroup ran on.
+// At B = 1 the plain kernel is 8 workgroups whose waves walk up to 4 pages one memory round trip after the other (4 -> 16 us from 256 to
+// 1024 tokens of context); split, every wave has one page and a launch is one round trip plus the merge whatever the context.
+// (Round 4 also built the merge INTO the consumer -- the kernel leaving partials only and the single-stream out-projection GEMV merging
+// them while loading its row, no counter at all: attention 6.35 -> 5.24 us and the GEMV 4.8 -> 5.3 in the kernel trace, but the B = 1 step
+// 174 us against 167.5 for the last-arriver merge, measured three times interleaved; removed.)
+template <int DH, bool F16, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict__ qkv, KvPool pool, int layer,
                                                         const int32_t* __restrict__ page_table, int max_pages,
                                                         const int32_t* __restrict__ ctx_len,
                                                         const int32_t* __restrict__ lens, float* __restrict__ out,
-                                                        int H, int T, int C, float scale, int tiled_out) {
+                                                        int H, int T, int C, float scale, int tiled_out, AttnSplit sp) {
     constexpr int G = F16 ? 8 : 4;     // elements per 16-byte group
     constexpr int EB = F16 ? 2 : 4;    // bytes per element
     constexpr int NCH = DH / G;        // 16-byte chunks per head row
@@ -84,17 +94,21 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     // (profiles/r3_attn_early_v_ab_by_ctx.txt: that burst, not a latency chain, was most of the 8.6 us a launch took at short
     // contexts).  Above 256 tokens their first pages are full and they start ~0.7 us later than wave 0, which has as many pages or
     // one more.
-    if (wave == 0) load_k(0, 64);
+    const int zsplit = SPLIT ? (int)blockIdx.z : 0, nsplit = SPLIT ? (int)gridDim.z : 1;
+    if (wave == 0 && zsplit == 0) load_k(0, 64);
 
     const int n_new = lens ? lens[b] : T;
     auto optr = [&](int d) { return tiled_out ? out + tiled_off((int)m, h * DH + d, C) : out + m * C + h * DH + d; };
     if (t >= n_new) {  // padded query row: defined output, never used
-        if (threadIdx.x < DH) *optr(threadIdx.x) = 0.f;
+        if (threadIdx.x < DH && zsplit == 0) *optr(threadIdx.x) = 0.f;
         return;
     }
     const int len = ctx_len[b] + n_new;  // tokens visible to this query (whole cache, no mask)
     const int npages = (len + 63) >> 6;
-    if (wave != 0 && wave < npages) load_k(wave, len - wave * 64);
+    const int active = SPLIT ? min(nsplit, (npages + 3) >> 2) : 1;   // splits that have a page
+    if (SPLIT && zsplit >= active) return;
+    const int pg0 = zsplit * 4 + wave, pg_step = 4 * nsplit;
+    if ((wave != 0 || zsplit != 0) && pg0 < npages) load_k(pg0, len - pg0 * 64);
 
     const float* qp = qkv + m * 3 * C + h * DH;
     float q[DH];
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < G; ++e) acc[e] = 0.f;
 
-    for (int pg = wave; pg < npages; pg += 4) {
+    for (int pg = pg0; pg < npages; pg += pg_step) {
         const char* vpage = page_base(pg, 1);
         const int n_tok = len - pg * 64;   // >= 1; > 64 for a full page
 #pragma unroll
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < G; ++e) acc[e] *= alpha;
         mx = mnew;
-        if (pg + 4 < npages) load_k(pg + 4, len - (pg + 4) * 64);  // K registers are free again: next page's K under PV
+        if (pg + pg_step < npages) load_k(pg + pg_step, len - (pg + pg_step) * 64);  // K registers are free again: next page's K under PV
 #pragma unroll
         for (int j = 0; j < NVI; ++j) {
             const float pv = __shfl(p, j * TPI + g, 64);
@@ -168,28 +182,92 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
         for (int e = 0; e < G; ++e) s_acc[wave][G * lane + e] = acc[e];
     }
     __syncthreads();
+    float M = 0.f, num = 0.f, den = 0.f;
     if (threadIdx.x < DH) {
-        const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        float num = 0.f, den = 0.f;
+        M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const float f = (s_m[w] == -INFINITY) ? 0.f : __expf(s_m[w] - M);  // waves without pages
             num = fmaf(f, s_acc[w][threadIdx.x], num);
             den = fmaf(f, s_l[w], den);
         }
-        *optr(threadIdx.x) = num / den;
     }
+    constexpr int PS = attn_part_floats(DH);   // floats per partial: acc[DH], max, sum (+ 2 of padding: 16-byte rows)
+    const int64_t item = (int64_t)bh * T + t;
+    float* part = sp.part + item * sp.max_split * PS;
+    if (!SPLIT || active == 1) {   // the only workgroup of this query: done
+        if (threadIdx.x < DH) *optr(threadIdx.x) = num / den;
+        return;
+    }
+    // ---- leave the partial, count the arrival; the last one merges
+    auto st_dev = [](float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_dev = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (threadIdx.x < DH) {
+        st_dev(part + zsplit * PS + threadIdx.x, num);
+        if (threadIdx.x == 0) { st_dev(part + zsplit * PS + DH, M); st_dev(part + zsplit * PS + DH + 1, den); }
+    }
+    // Hand-off without cache-maintenance fences (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms": a buffer_inv sc1 alone
+    // is ~1.7 us, three of them made this form SLOWER than the plain kernel -- 180.0 against 176.9 us per B = 1 step): every store of
+    // the partial is an sc1 (write-through, device-scope) store and is drained by its wave (vmcnt 0) before the workgroup's barrier;
+    // then ONE lane adds to the counter with a device-scope atomic; the workgroup whose add returns active - 1 loads the partials, after
+    // a barrier behind that add, with sc1 loads only (they bypass the L1 and the XCD's L2).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(sp.count + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == active - 1;
+        if (s_last) __hip_atomic_store(sp.count + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < DH) {
+        // every partial requested before the first is used (clamped indices past `active`): one memory round trip, not one per split
+        float pm[MGEA_ATTN_MAX_SPLIT], pl[MGEA_ATTN_MAX_SPLIT], pa[MGEA_ATTN_MAX_SPLIT];
+#pragma unroll
+        for (int z = 0; z < MGEA_ATTN_MAX_SPLIT; ++z) {
+            const float* pz = part + (z < active ? z : 0) * PS;
+            pm[z] = ld_dev(pz + DH); pl[z] = ld_dev(pz + DH + 1); pa[z] = ld_dev(pz + threadIdx.x);
+        }
+        float Mall = -INFINITY;
+#pragma unroll
+        for (int z = 0; z < MGEA_ATTN_MAX_SPLIT; ++z) Mall = z < active ? fmaxf(Mall, pm[z]) : Mall;
+        float n = 0.f, d = 0.f;
+#pragma unroll
+        for (int z = 0; z < MGEA_ATTN_MAX_SPLIT; ++z) {   // split order, whoever arrived last: deterministic
+            const float f = z < active ? __expf(pm[z] - Mall) : 0.f;
+            n = fmaf(f, pa[z], n);
+            d = fmaf(f, pl[z], d);
+        }
+        *optr(threadIdx.x) = n / d;
+    }
+}
+
+int attn_split_count(int B, int H, int T, int max_pages) {
+    // worth it only while the plain grid leaves the chip short of waves to hide the page round trips behind each other, and only for
+    // the decode step's single query per row.  The switch's value is the largest number of (row, head) pairs that are split.
+    const int limit = tune(TUNE_ATTN_SPLIT);
+    if (limit <= 0 || T != 1 || B * H > limit || B * H > MGEA_ATTN_SPLIT_ITEMS || max_pages <= 4) return 1;
+    int s = (max_pages + 3) / 4;
+    const int room = 512 / (B * H);   // up to two workgroups per CU
+    if (s > room) s = room;
+    if (s > MGEA_ATTN_MAX_SPLIT) s = MGEA_ATTN_MAX_SPLIT;
+    return s < 1 ? 1 : s;
 }
 
 int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int32_t* page_table, int max_pages,
                       const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T, int C, int tiled_out,
-                      hipStream_t st) {
+                      hipStream_t st, const AttnSplit* split) {
     const int H = pool.H, dh = pool.dh;
     MGEA_REQUIRE(H * dh == C, MGEA_EINVAL, "attention: n_head*head_dim != d_model");
     MGEA_REQUIRE(T <= 65535, MGEA_EINVAL, "attention: too many new tokens per row (%d)", T);
     const float scale = 1.0f / sqrtf((float)dh);
-    dim3 grid(B * H, T);
-#define MGEA_ATTN(DH, F) hipLaunchKernelGGL((attn_paged_kernel<DH, F>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out)
+    const int ns = split && split->part && split->count ? attn_split_count(B, H, T, max_pages) : 1;
+    MGEA_REQUIRE(ns == 1 || (ns <= split->max_split && B * H * T <= split->max_items), MGEA_EINVAL, "attention: split scratch too small");
+    dim3 grid(B * H, T, ns);
+    const AttnSplit sp = split ? *split : AttnSplit{};
+#define MGEA_ATTN(DH, F) do { if (ns > 1) hipLaunchKernelGGL((attn_paged_kernel<DH, F, true>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); \
+                              else hipLaunchKernelGGL((attn_paged_kernel<DH, F, false>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); } while (0)
     if (pool.f16) {
         switch (dh) {
             case 32: MGEA_ATTN(32, true); break;

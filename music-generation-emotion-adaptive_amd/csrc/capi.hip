@@ -42,6 +42,7 @@ const TuneEntry kTune[] = {
     {TUNE_ATTN16_PIPE, "attn16_pipe", "MGEA_ATTN16_PIPE", 1},
     {TUNE_SKINNY_ONE_PER_CU, "skinny_one_per_cu", "MGEA_SKINNY_ONE_PER_CU", 0},
     {TUNE_SAMPLER_WAVE_SELECT, "sampler_wave_select", "MGEA_SAMPLER_WAVE_SELECT", 1},
+    {TUNE_ATTN_SPLIT, "attn_split", "MGEA_ATTN_SPLIT", 64},
 };
 static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];

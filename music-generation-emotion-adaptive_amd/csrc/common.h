@@ -57,6 +57,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_ATTN16_PIPE,          // 1 (default): the 16-bit flash attention runs full key stages software-pipelined (next tile's Q K^T under this tile's exponentials); 0: rolled loop
        TUNE_SKINNY_ONE_PER_CU,    // 1: skinny GEMM launches of <= 256 workgroups ask for > 80 KB of LDS, so that no two share a CU (A/B; default 0)
        TUNE_SAMPLER_WAVE_SELECT,  // 1 (default): top_k <= 64 finds its boundary wave by wave (ballots only) and merges 4 x 64 candidates after one barrier; 0: block-wide bisection, a barrier per bit
+       TUNE_ATTN_SPLIT,           // the decode step's attention of at most this many (row, head) pairs spreads each pair's KV pages over several workgroups, the last one to arrive merges their partials (default 64 = 8 rows of 8 heads: measured +3..5 % tokens/s at 1-8 rows, nothing at 16, -3.5 % at 32; 0: always one workgroup per pair)
        TUNE_COUNT };
 int tune(int key);
 
@@ -164,9 +165,16 @@ int launch_qkv_scatter(const float* P, int S, int64_t ps, int ldp, const float* 
                        const int32_t* ctx_len, const int32_t* lens, int B, int T, int C, hipStream_t st);
 // decode / extend attention over the paged cache: query rows m = b*T + t attend to
 // ctx_len[b] + (lens ? lens[b] : T) cached tokens.  q read from qkv[m, 0:C] (row stride 3C).
+// split (small batches): scratch of the split-context form -- part [max_items][max_split][attn_part_floats(dh)] floats, count
+// [max_items] int32 zeroed once (the kernel leaves them zero); NULL, or a shape attn_split_count() answers 1 for: one workgroup per
+// (row, head, query).
+constexpr int MGEA_ATTN_MAX_SPLIT = 16, MGEA_ATTN_SPLIT_ITEMS = 256;
+__host__ __device__ constexpr int attn_part_floats(int dh) { return dh + 2; }   // acc[dh], max, sum
+struct AttnSplit { float* part; int32_t* count; int max_split, max_items; };
+int attn_split_count(int B, int H, int T, int max_pages);
 int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int32_t* page_table,
                       int max_pages, const int32_t* ctx_len, const int32_t* lens, float* out, int B, int T,
-                      int C, int tiled_out, hipStream_t st);
+                      int C, int tiled_out, hipStream_t st, const AttnSplit* split = nullptr);
 // dense non-causal attention over the qkv buffer itself (prefill without past, BERT)
 int launch_attn_dense(const float* qkv, const int32_t* lens, const int32_t* mask, float* out, int B, int T,
                       int H, int dh, int tiled_out, hipStream_t st, const int32_t* cu = nullptr);   // cu: packed rows (T = the longest sequence)

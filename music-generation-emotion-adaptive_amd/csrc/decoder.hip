@@ -109,6 +109,7 @@ struct mgea_decoder {
     uint64_t use_clock = 0;
     SamplerParams* samp_dev = nullptr;
     int32_t* err_flag = nullptr;   // sticky device flags (bit 0: a token id outside the vocabulary was clamped)
+    AttnSplit attn_split{};        // scratch of the split-context decode attention (small batches; attn_paged.hip)
     int64_t counters[8] = {0};
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_stride = 0;  // 0 = off; n = time every n-th decode step of generate(), run eagerly
@@ -299,7 +300,7 @@ int run_blocks(mgea_decoder* h, int B, int T, const int32_t* lens, bool use_cach
         if (kv_only_last && scatter && l + 1 == c.n_layer) break;
         if (use_cache_attn) {
             PROF(PC_ATTN_PAGED, launch_attn_paged(h->qkv, h->kv, l, h->page_table, h->max_pages, h->ctx_len, lens, h->att, B, T,
-                                       C, 0, st));
+                                       C, 0, st, &h->attn_split));
         } else {
             PROF(PC_ATTN_DENSE, launch_attn_dense(h->qkv, lens, nullptr, h->att, B, T, c.n_head, h->dh, 0, st));
         }
@@ -386,7 +387,7 @@ int run_blocks_fused(mgea_decoder* h, const Bufs& u, int B, int T, const int32_t
         }
         if (kv_only_last && l + 1 == c.n_layer) break;       // (run_blocks: the logits are dropped, the last block's K | V are appended)
         if (use_cache_attn) {
-            PROF(PC_ATTN_PAGED, launch_attn_paged(u.qkv, h->kv, l, u.page_table, h->max_pages, u.ctx_len, lens, u.att, B, T, C, 1, st));
+            PROF(PC_ATTN_PAGED, launch_attn_paged(u.qkv, h->kv, l, u.page_table, h->max_pages, u.ctx_len, lens, u.att, B, T, C, 1, st, &h->attn_split));
         } else {
             PROF(PC_ATTN_DENSE, launch_attn_dense(u.qkv, lens, nullptr, u.att, B, T, c.n_head, h->dh, 1, st));
         }
@@ -937,6 +938,12 @@ int mgea_decoder_create(const mgea_decoder_config* cfg, const float* arena_dev, 
         hipMalloc((void**)&h->err_flag, 16) != hipSuccess ||
         hipMalloc((void**)&h->ids_hist, nb * h->ids_hist_stride) != hipSuccess)
         return fail(MGEA_ENOMEM, "state allocation failed");
+    h->attn_split.max_split = MGEA_ATTN_MAX_SPLIT;
+    h->attn_split.max_items = MGEA_ATTN_SPLIT_ITEMS;   // attn_split_count(): (row, head) pairs, one query each
+    if (hipMalloc((void**)&h->attn_split.part, (size_t)MGEA_ATTN_SPLIT_ITEMS * MGEA_ATTN_MAX_SPLIT * attn_part_floats(h->dh) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&h->attn_split.count, MGEA_ATTN_SPLIT_ITEMS * sizeof(int32_t)) != hipSuccess)
+        return fail(MGEA_ENOMEM, "state allocation failed");
+    (void)hipMemset(h->attn_split.count, 0, MGEA_ATTN_SPLIT_ITEMS * sizeof(int32_t));
     (void)hipMemset(h->page_table, 0, nb * h->max_pages);
     (void)hipMemset(h->ctx_len, 0, nb);
     (void)hipMemset(h->done, 0, nb);
@@ -976,7 +983,7 @@ int mgea_decoder_destroy(mgea_decoder* h) {
     free_ws(h);
     free_p16(h);
     void* p[] = {h->kv.base, h->page_table, h->ctx_len, h->cur_ids, h->done, h->row_step, h->n_done, h->sampled, h->ids_hist, h->wt, h->lnv,
-                 h->samp_dev, h->err_flag, h->arena_own};
+                 h->samp_dev, h->err_flag, h->arena_own, h->attn_split.part, h->attn_split.count};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete h;

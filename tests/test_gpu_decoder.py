@@ -472,6 +472,51 @@ def test_prefill_whose_logits_are_dropped_stops_at_the_last_blocks_kv(golden, pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_rows", [1, 3, 8])
+def test_split_context_decode_attention_vs_one_workgroup_per_head_and_oracle(n_rows, tune):
+    """Round 4: with at most 64 (row, head) pairs the decode step's attention spreads a pair's KV pages over several workgroups and the
+    last one to arrive merges their partials (attn_paged.hip, switch attn_split).  Decoder-S geometry, ragged contexts that need 1, 2, 3
+    and 4 splits (and rows that need one next to rows that need four), against the one-workgroup form: step logits within fp32
+    summation noise and greedy ids equal over steps that cross page and split boundaries, eagerly and under the captured graph; the
+    first step's logits against the oracle as well."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    torch.set_num_threads(16)
+    vocab = 8324
+    sd = synth.decoder_state_dict(23, vocab, 1024, 512, 6)
+    lens_l = [1000, 255, 64, 513, 1, 767, 257, 900][:n_rows]
+    T = max(lens_l)
+    idx = torch.from_numpy(synth.integers(43, "split", (n_rows, T), 0, vocab)).long()
+    valid = torch.arange(T)[None, :] < torch.tensor(lens_l)[:, None]
+    idx = idx * valid
+    lens = torch.tensor(lens_l, dtype=torch.int32)
+    runs = []
+    for sw in (0, 256):           # the switch's value: the largest number of (row, head) pairs that are split
+        tune("attn_split", sw)
+        eng = DecoderEngine(sd, n_head=8, max_batch=8, max_ctx=1024)
+        samp = eng.sampler(1.0, 1)
+        eng.reset_and_prefill(idx, lens, want_logits=False, max_len=1024)
+        steps = [eng.step(None, samp, want_logits=True) for _ in range(4)]
+        prompts = [idx[b, :n].tolist() for b, n in enumerate(lens_l)]
+        out = eng.generate(prompts, 24, top_k=1).cpu()        # the captured graph, contexts growing across page boundaries
+        runs.append(([(i.cpu(), l.cpu()) for i, l in steps], out))
+        eng.close()
+    for other in runs[1:]:
+        for (i0, l0), (i1, l1) in zip(runs[0][0], other[0]):
+            assert torch.equal(i0, i1)
+            assert float((l0 - l1).abs().max()) < 2e-5
+        assert torch.equal(runs[0][1], other[1])
+    if n_rows <= 3:
+        ref = DecoderRef(sd, 8)
+        _, cache, cvalid = ref.forward(idx, None, None, valid)
+        last = idx[torch.arange(n_rows), torch.tensor(lens_l) - 1][:, None]
+        want, _, _ = ref.forward(last, cache, cvalid, None)
+        err = float((runs[1][0][0][1] - want[:, -1]).abs().max())
+        print(f"split-context decode step, {n_rows} rows: max |logit diff| vs oracle = {err:.2e}")
+        assert err < LOGIT_TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["ragged_4x1000", "full_8x1024", "bench_64x1024"])
 def test_f32_long_prompt_prefill_and_decode_from_its_pages_vs_oracle(shape):
     """GPTWithKV.forward returns logits for any T <= SEQ_LEN (api_cache.py:87-106), and `bench.py: extra.decoder_prefill` times the f32

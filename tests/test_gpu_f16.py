@@ -125,12 +125,16 @@ def test_f16_prefill_logits_against_oracle_on_rounded_weights(golden):
     assert float((lg.cpu() - want[:, -1]).abs().max()) < F16_LOGIT_TOL
 
 
-def test_f16_config4_as_written_2048_tokens_top_p_through_the_graph():
+def test_f16_config4_as_written_2048_tokens_top_p_through_the_graph(tune):
     """BASELINE configs[4]: 12-layer / 768-dim decoder, top-p = 0.9 sampling, 2048-token generation, fp16, hipGraph-captured
     decode step (here 8 of the 64 rows one GPU gets).  The oracle cannot follow 2043 sampled steps, so at full length the
-    checks are size-independent properties; the arithmetic of the same engine is pinned by the teacher-forced test above."""
+    checks are size-independent properties; the arithmetic of the same engine is pinned by the teacher-forced test above.
+    Batch-composition independence holds within one form of the decode attention: up to 64 (row, head) pairs it spreads a pair's pages
+    over several workgroups (round 4, switch attn_split), above that one workgroup walks them -- two summation orders, so a 3-row batch is
+    compared with the 8-row one (96 pairs) with the switch at 0, and with a 2-row batch at the default."""
     from mgea.decoder import DecoderEngine
     sd = synth.decoder_state_dict(5, 8324, 2048, 768, 12)
+    tune("attn_split", 0)
     eng = DecoderEngine(sd, n_head=12, max_batch=8, max_ctx=2048, dtype="f16")
     prompts = synth.integers(1, "p", (8, 5), 0, 8324).tolist()
     n = 2048 - 5
@@ -151,6 +155,24 @@ def test_f16_config4_as_written_2048_tokens_top_p_through_the_graph():
     g1 = eng.generate(prompts, n, top_k=1).cpu()
     g2 = eng.generate([prompts[i] for i in (5, 2)], n, top_k=1).cpu()
     assert torch.equal(g2[0], g1[5]) and torch.equal(g2[1], g1[2])
+    eng.close()
+    # the split form (default switch; 3 and 2 rows x 12 heads are both below its limit): same properties among its own batches,
+    # including the merge by whichever workgroup arrives last -- run to run and batch to batch bit-identical
+    tune("attn_split", 64)
+    eng = DecoderEngine(sd, n_head=12, max_batch=8, max_ctx=2048, dtype="f16")
+    s3 = eng.generate([prompts[i] for i in (0, 3, 7)], n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    s3b = eng.generate([prompts[i] for i in (0, 3, 7)], n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    s2 = eng.generate([prompts[i] for i in (0, 3)], n, temperature=1.0, top_k=None, top_p=0.9, seed=11).cpu()
+    assert torch.equal(s3, s3b) and torch.equal(s2[0], s3[0])
+    assert eng.context_lengths().cpu().tolist() == [2048] * 2
+    g3 = eng.generate([prompts[i] for i in (5, 2, 0)], n, top_k=1).cpu()
+    g4 = eng.generate([prompts[i] for i in (5, 2)], n, top_k=1).cpu()
+    assert torch.equal(g3[:2], g4)
+    # (against the other form the greedy ids of this random-weight model part ways at some fp16 near-tie within 2043 steps: two summation
+    # orders of the same attention; each form is held to the oracle by the teacher-forced tests)
+    first = int((g3[0] != g1[5]).nonzero()[0]) if not torch.equal(g3[0], g1[5]) else n
+    print(f"config 4 greedy, split vs one-workgroup attention: identical for the first {first} of {n} steps")
+    eng.close()
 
 
 def test_f16_structure_rows_eos_and_refresh(golden):

@@ -52,6 +52,9 @@ for s in $STEPS; do
     sampler)   run samplertests 600 python3 -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "sampler or topk" || exit 1
                MGEA_SAMPLER_WAVE_SELECT=0 run sampler_old 200 python3 tools/sampler_bench.py || exit 1
                run sampler_new 200 python3 tools/sampler_bench.py || exit 1 ;;
+    splittests) run splittests 900 python3 -m pytest tests/test_gpu_decoder.py -x -q -m gpu -s -k "split_context or full_context or single_stream or fused_path_step or generate_vs_oracle" || exit 1 ;;
+    b1)        MGEA_ATTN_SPLIT=0 run b1_old 300 python3 tools/b1_prof.py || exit 1
+               run b1_new 300 python3 tools/b1_prof.py || exit 1 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
