@@ -511,7 +511,7 @@ def main():
             if os.path.exists(kst):
                 import csv
                 for r in csv.DictReader(open(kst)):
-                    if "attn_paged_kernel<64, false>" in r["Name"]:
+                    if "attn_paged_kernel<64, false" in r["Name"]:      # <64, false, false> since the SPLIT parameter (round 4)
                         t_us = float(r["AverageNs"]) / 1e3
                         alg = B * N_HEAD * 2 * (Tp + (n_steps - 1) / 2 + 1) * dh * 4     # mean over all steps of the generation
                         trace = dict(avg_launch_us=t_us, launches=int(r["Calls"]), achieved=alg / (t_us * 1e-6) / 1e9,
