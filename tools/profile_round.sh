@@ -55,6 +55,8 @@ step head_phases 300 python3 tools/head_phases.py
 step step_ab_head 300 python3 tools/step_ab.py head_balanced 0 1
 step step_ab_one_per_cu 300 python3 tools/step_ab.py skinny_one_per_cu 0 1
 step sampler_bench 200 python3 tools/sampler_bench.py
+# (round 4) the reference's own serving case, B = 1: kernel stats of one greedy generation (split-context decode attention)
+step b1_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $T/b1 -- python3 tools/b1_prof.py && stats $T/b1 $OUT/b1_kernel_stats.csv
 # MFMA utilisation of the DistilBERT GEMMs
 step pmc_mfma 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-include-regex gemm_bf16_ph_kernel --output-format csv -d $T/pmc_mfma -- python3 tools/bert_prof.py bf16
 f=$(pmc $T/pmc_mfma); [ -n "$f" ] && python3 tools/pmc_mfma.py $f gemm > $OUT/pmc_mfma_util.json
