@@ -5,7 +5,8 @@
 // One 256-thread workgroup per row; the row lives in registers (thread t owns logits t, t + 256, ...), nothing is sorted.  (Round 4 measured
 // two ways of spending more hardware on a row, both NEUTRAL: 1024 threads per row -- 21.9 / 32.3 us for top-k / top-p at B = 64, V = 8324
 // against 20 / 31.9 -- and per-lane counters with one DPP reduction per pass instead of a ballot + s_bcnt1 per logit -- 22.8 us.  What did
-// pay is taking the row out of the passes: "top-k without a pass over the row per bit" below, 21.0 -> 11.5 us.)
+// pay is taking the row out of the passes: "top-k without a pass over the row per bit" and "top-p without a top-k" below, 21.0 -> 11.5
+// and 29.6 -> 20.5 us.)
 //   * top-k : exact k-th largest logit by bit-wise bisection of order-preserving uint keys (integer counts ->
 //             deterministic), over a pivot-selected candidate list for top_k <= 64, over the registers otherwise; kept = {logit > k-th} plus as many of the
 //             entries EQUAL to the k-th as it takes to keep exactly k, lowest ids first (topk + scatter_ of
@@ -13,7 +14,8 @@
 //             unspecified, lowest-id is this build's rule).  exp(-1e10) underflows to exactly 0 in fp32, so
 //             "mask then softmax" == "softmax over kept".
 //   * top-p : the nucleus {i : mass of strictly larger logits < top_p} by the same bisection over
-//             fixed-point (2^-40) probability masses (64-bit integer sums -> deterministic);
+//             fixed-point (2^-40) probability masses (64-bit integer sums -> deterministic), over the candidates of the
+//             top-k path or of a mass histogram ("top-p without a top-k" below), over the registers otherwise;
 //             kept = {logit >= boundary}.
 //   * draw  : u from Philox4x32-10 keyed (seed; row, step); inverse CDF over the kept set in
 //             thread-major order (any fixed order gives the same distribution).  torch.multinomial's
@@ -57,15 +59,28 @@ __device__ __forceinline__ float block_sum_f(float v, float* red /* [SAMP_NW] */
     return t;
 }
 
-// xor-butterfly sum over each aligned group of 16 lanes with DPP (a few cycles per step), then across the four groups
+// Whole-wave reductions on DPP alone (no LDS crossbar: a ds_bpermute round trip is ~100+ cycles, and the bisections below reduce once or
+// twice per pass): butterfly inside each row of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 (gfx9 DPP
+// controls), the result read from lane 63 -- wave-uniform, in a scalar register.
+#define MGEA_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xF, true)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
-    v += (uint32_t)__shfl_xor((int)v, 16, 64);
-    v += (uint32_t)__shfl_xor((int)v, 32, 64);
-    return v;
+    v += (uint32_t)MGEA_DPP(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    v += (uint32_t)MGEA_DPP(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    v += (uint32_t)MGEA_DPP(v, 0x141, 0xF);   // row_half_mirror
+    v += (uint32_t)MGEA_DPP(v, 0x140, 0xF);   // row_mirror: every lane holds its row's sum
+    v += (uint32_t)MGEA_DPP(v, 0x142, 0xA);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)MGEA_DPP(v, 0x143, 0xC);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {   // rows not written by a masked step see 0: neutral for an unsigned maximum
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0xB1, 0xF));
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0x4E, 0xF));
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0x141, 0xF));
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0x140, 0xF));
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0x142, 0xA));
+    v = umax32(v, (uint32_t)MGEA_DPP(v, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Boundary search shared by top-k (weights = 1, target = k) and top-p (weights = fixed-point mass): the largest key t
@@ -129,8 +144,39 @@ __device__ __forceinline__ uint32_t bisect_boundary(const uint32_t (&key)[MAXE],
 // bisection.  Integer counts throughout: same boundary key either way.  top_k <= SAMP_KFAST takes this path.
 constexpr int SAMP_KFAST = 64;
 
+// p (a probability, <= 1) as the 2^-40 fixed-point integer floor(p * 2^40), split as hi = bits 20.., lo = bits 0..19 -- the integers the
+// mass sums are made of.  All float operations below are exact (powers of two, an integer part, a remainder), so this is the same integer
+// as (unsigned long long)((double)p * 2^40) at a third of the instructions (no f64, no 64-bit conversion).
+__device__ __forceinline__ void mass_fixed(float p, uint32_t& hi, uint32_t& lo) {
+    const float t = p * 1048576.0f;
+    hi = (uint32_t)t;
+    lo = (uint32_t)((t - (float)hi) * 1048576.0f);
+}
+
+// The non-zero keys a wave holds lie in [lo, hi]: every boundary the bisections below look for does too, so the bits above the highest
+// bit in which lo and hi differ are already known.  Returns that common prefix and the number of low bits left to decide (32: nothing
+// known -- no non-zero key at all, or keys on both sides of the top bit).
+template <int N>
+__device__ __forceinline__ uint32_t wave_common_prefix(const uint32_t (&key)[N], int* nbits) {
+    uint32_t hi = 0u, lo_inv = 0u;   // lo via the maximum of the complements
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        hi = hi > key[j] ? hi : key[j];
+        const uint32_t c = key[j] != 0u ? ~key[j] : 0u;
+        lo_inv = lo_inv > c ? lo_inv : c;
+    }
+    hi = wave_max_u32(hi);
+    const uint32_t lo = ~wave_max_u32(lo_inv);   // 0xFFFFFFFF when there is no non-zero key
+    const uint32_t diff = hi ^ lo;
+    const int nb = (hi == 0u) ? 32 : 32 - __clz((int)diff);   // diff == 0: one distinct key, nothing left to decide (clz(0) = 32)
+    *nbits = nb;
+    return nb >= 32 ? 0u : (hi >> nb) << nb;
+}
+
 template <int N>
 __device__ __forceinline__ uint32_t wave_kth_largest(const uint32_t (&key)[N], uint32_t k) {   // 0 when fewer than k keys are non-zero
+    // (starting below the keys' common prefix, as wave_mass_boundary does, was measured here too: the two wave reductions cost more than
+    // the ~10 passes of N compares they save -- top-k 50 at 12.2 us against 11.5)
     uint32_t prefix = 0u;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit);
@@ -162,18 +208,72 @@ __device__ __forceinline__ int wave_publish_ge(const uint32_t (&key)[N], uint32_
     return base;
 }
 
+// ---- top-p without a top-k (or behind one larger than SAMP_KFAST): no count bounds the nucleus, so the candidates come from a mass
+// histogram instead.  Bucket = floor((max - x) * SAMP_HSCALE), 256 of them over the 28 units below the maximum beyond which a
+// probability rounds to 0 in the 2^-40 fixed point: non-increasing in the key, so the buckets are ordered slices of the sorted row.
+//   1. one pass adds every entry's fixed-point mass to its bucket (64-bit LDS atomics: integer sums, order-free);
+//   2. every wave scans the 256 buckets (4 per lane) for the first one at which the running mass reaches the target: the nucleus
+//      boundary lies in it, and everything in the buckets before it is kept;
+//   3. one pass writes that bucket's keys into the wave's 64 LDS slots; every wave bisects those <= 4 x 64 candidates for the largest
+//      key at which (mass before the bucket + mass of the candidates at or above it) reaches the target.
+// Same integers as the block-wide bisection -> same boundary key.  More than 64 candidates in a wave: the block-wide bisection.
+constexpr float SAMP_HSCALE = 256.0f / 28.0f;
+
+__device__ __forceinline__ int mass_bucket(float mx, float x) {
+    const int b = (int)((mx - x) * SAMP_HSCALE);   // v_cvt_i32_f32: NaN -> 0, +inf saturates
+    return (unsigned)b > 255u ? 255 : b;
+}
+
+// first bucket whose inclusive running mass reaches `target`, and the mass before it; -1 when the whole row weighs less
+__device__ __forceinline__ int wave_find_bucket(const unsigned long long* hist /* [256] in LDS */, unsigned long long target,
+                                                unsigned long long* before) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long h[4], c[5];
+    c[0] = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = hist[4 * lane + i]; c[i + 1] = c[i] + h[i]; }
+    unsigned long long inc = c[4];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    const unsigned long long excl = inc - c[4];
+    const unsigned long long hit = __ballot(inc >= target);
+    if (hit == 0ull) { *before = 0ull; return -1; }
+    const int L = __ffsll((long long)hit) - 1;
+    int i = 0;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) i = excl + c[q + 1] >= target ? q : i;   // first of my four that reaches it
+    unsigned long long bef = excl + (i == 0 ? c[0] : i == 1 ? c[1] : i == 2 ? c[2] : c[3]);
+    const int b = __shfl(4 * lane + i, L, 64);
+    *before = __shfl(bef, L, 64);
+    return b;
+}
+
 // the mass bisection of bisect_boundary<true> over candidates a single wave holds (R per lane): same integers, same boundary
 template <int R>
 __device__ __forceinline__ uint32_t wave_mass_boundary(const uint32_t (&key)[R], const uint32_t (&whi)[R], const uint32_t (&wlo)[R],
                                                        uint32_t floor_key, unsigned long long target) {
-    uint32_t prefix = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
+    // candidates that count: key >= floor_key and non-zero (the others carry no mass: whi = wlo = 0)
+    uint32_t live[R];
+    uint32_t hi = 0u, lo = 0u;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        live[j] = (key[j] >= floor_key && (whi[j] | wlo[j]) != 0u) ? key[j] : 0u;
+        hi += live[j] != 0u ? whi[j] : 0u;
+        lo += live[j] != 0u ? wlo[j] : 0u;
+    }
+    const unsigned long long all = ((unsigned long long)wave_sum_u32(hi) << 20) + wave_sum_u32(lo);
+    if (all < target) return floor_key;   // even everything weighs less: the bisection would end at prefix 0
+    int nbits;
+    uint32_t prefix = wave_common_prefix<R>(live, &nbits);   // mass({key >= lowest live key}) = all >= target: the boundary is among them
+    for (int bit = nbits - 1; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit);
-        const uint32_t lim = cand > floor_key ? cand : floor_key;
-        uint32_t hi = 0u, lo = 0u;
+        hi = 0u; lo = 0u;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const bool in = key[j] >= lim;
+            const bool in = live[j] >= cand;
             hi += in ? whi[j] : 0u;
             lo += in ? wlo[j] : 0u;
         }
@@ -199,6 +299,8 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
     static_assert(SAMP_KFAST == 64, "wave_publish_ge fills one slot per lane");
     __shared__ unsigned long long red64[2 * NW];
     __shared__ uint32_t s_cand[NW * SAMP_KFAST];
+    __shared__ unsigned long long s_hist[NT];
+    static_assert(NT == 256, "the mass histogram has one bucket per thread");
     __shared__ int s_tie[NW], s_fit[NW];
     if (pd) pv = *pd;   // device-resident scalars (one 32-byte scalar load) win over the by-value copy
     const float temperature = pv.temperature, top_p = pv.top_p;
@@ -322,23 +424,53 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < NW; ++r) {
                 chi[r] = clo[r] = 0u;
-                if (cand[r] != 0u && cand[r] >= keep_key) {
-                    const unsigned long long w = (unsigned long long)((double)(__expf(funkey(cand[r]) - mx) * invZ) * 1099511627776.0);
-                    chi[r] = (uint32_t)(w >> 20);
-                    clo[r] = (uint32_t)(w & 0xFFFFFu);
-                }
+                if (cand[r] != 0u && cand[r] >= keep_key) mass_fixed(__expf(funkey(cand[r]) - mx) * invZ, chi[r], clo[r]);
             }
             keep_key = wave_mass_boundary<NW>(cand, chi, clo, keep_key, target);
         } else {
 #pragma unroll
             for (int j = 0; j < MAXE; ++j) {
-                if (key[j] != 0u && key[j] >= keep_key) {
-                    const unsigned long long w = (unsigned long long)((double)(__expf(x[j] - mx) * invZ) * 1099511627776.0);
-                    whi[j] = (uint32_t)(w >> 20);   // <= 2^20: 64 lanes x MAXE of them stay below 2^32
-                    wlo[j] = (uint32_t)(w & 0xFFFFFu);
+                if (key[j] != 0u && key[j] >= keep_key) mass_fixed(__expf(x[j] - mx) * invZ, whi[j], wlo[j]);   // hi <= 2^20: 64 lanes x MAXE of them stay below 2^32
+            }
+            bool done = false;
+            if (wave_select) {
+                s_hist[tid] = 0ull;   // NT == 256 buckets
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < MAXE; ++j) {
+                    const unsigned long long w = ((unsigned long long)whi[j] << 20) + wlo[j];
+                    if (w != 0ull) atomicAdd(&s_hist[mass_bucket(mx, x[j])], w);
+                }
+                __syncthreads();
+                unsigned long long before = 0ull;
+                const int bstar = wave_find_bucket(s_hist, target, &before);   // the same in every wave
+                if (bstar < 0) {
+                    done = true;   // even everything weighs less than the target: keep all of it (keep_key stays the floor)
+                } else {
+                    uint32_t inb[MAXE];   // the keys of that bucket (0 elsewhere)
+#pragma unroll
+                    for (int j = 0; j < MAXE; ++j) inb[j] = ((whi[j] | wlo[j]) != 0u && mass_bucket(mx, x[j]) == bstar) ? key[j] : 0u;
+                    const int n_w = wave_publish_ge<MAXE>(inb, 1u, s_cand + (tid >> 6) * SAMP_KFAST);
+                    if ((tid & 63) == 0) s_fit[tid >> 6] = n_w;
+                    __syncthreads();
+                    bool fits = true;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) fits = fits && s_fit[w] <= SAMP_KFAST;
+                    if (fits) {
+                        uint32_t chi[NW], clo[NW];
+#pragma unroll
+                        for (int r = 0; r < NW; ++r) {
+                            cand[r] = s_cand[(tid & 63) + 64 * r];
+                            chi[r] = clo[r] = 0u;
+                            if (cand[r] != 0u) mass_fixed(__expf(funkey(cand[r]) - mx) * invZ, chi[r], clo[r]);
+                        }
+                        keep_key = wave_mass_boundary<NW>(cand, chi, clo, keep_key, target - before);
+                        done = true;
+                    }
+                    __syncthreads();   // s_fit / s_cand / red64 are reused by the fallback
                 }
             }
-            keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
+            if (!done) keep_key = bisect_boundary<true, MAXE>(key, whi, wlo, keep_key, target, red64);
         }
     }
 

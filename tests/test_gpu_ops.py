@@ -155,12 +155,18 @@ def test_topk_wave_by_wave_selection_equals_the_block_wide_bisection(ops, tune):
     tie[1, ::256] = 1.0; tie[1, 3] = 2.0                     # one wave's lanes hold all the large entries
     tie[2] = torch.randn(8324, generator=g).round()          # few distinct values: ties everywhere
     rows.append(tie)
+    rows.append(torch.randn(3, 8324, generator=g) * 12)       # peaked: the nucleus is a handful of entries, most masses round to 0
+    rows.append(torch.zeros(2, 8324))                         # flat: every entry in one histogram bucket (falls back to the block-wide passes)
+    rows.append(torch.randn(2, 8324, generator=g) * 0.05)     # nearly flat: a few buckets, hundreds of candidates each
     rows.append(torch.cat([torch.full((1, 300), float("-inf")), torch.randn(1, 200, generator=g)], 1))   # -inf entries
     for lg in rows:
         V = lg.shape[1]
         for k, pth, temp in [(1, 0.9, 1.0), (2, None, 1.0), (7, 0.3, 0.7), (50, None, 1.0), (50, 0.9, 1.3), (63, 0.5, 1.0), (64, None, 1.0),
-                             (64, 0.999, 1.0), (65, None, 1.0)]:
-            if k >= V:
+                             (64, 0.999, 1.0), (65, None, 1.0),
+                             # the nucleus cut WITHOUT a small top-k: candidates from the mass histogram (sampler.hip, "top-p without a top-k")
+                             (None, 0.9, 1.0), (None, 0.3, 0.7), (None, 0.999, 1.0), (None, 0.01, 1.0), (None, 0.5, 0.05), (200, 0.5, 1.0),
+                             (100, 0.95, 1.3), (65, 0.9, 1.0)]:
+            if k is not None and k >= V:
                 continue
             out = []
             for sw in (0, 1):
@@ -170,7 +176,7 @@ def test_topk_wave_by_wave_selection_equals_the_block_wide_bisection(ops, tune):
             assert torch.equal(out[0][0], out[1][0]), (V, k, pth)
             assert torch.equal(out[0][1], out[1][1]), (V, k, pth)
             kept = (out[1][1] > 0).sum(1)
-            assert bool((kept <= k).all()) and bool((kept >= 1).all())
+            assert bool((kept >= 1).all()) and (k is None or bool((kept <= k).all()))
             if pth is None and bool(torch.isfinite(lg).all()):
                 assert bool((kept == k).all())
 
