@@ -209,18 +209,20 @@ __device__ __forceinline__ int wave_publish_ge(const uint32_t (&key)[N], uint32_
 }
 
 // ---- top-p without a top-k (or behind one larger than SAMP_KFAST): no count bounds the nucleus, so the candidates come from a mass
-// histogram instead.  Bucket = floor((max - x) * SAMP_HSCALE), 256 of them over the 28 units below the maximum beyond which a
-// probability rounds to 0 in the 2^-40 fixed point: non-increasing in the key, so the buckets are ordered slices of the sorted row.
+// histogram instead.  Bucket = floor((max - x) * scale), 256 of them over the row's own span below its maximum -- or over the 28
+// units beyond which a probability rounds to 0 in the 2^-40 fixed point, if the row spans more -- non-increasing in the key, so the
+// buckets are ordered slices of the sorted row.  (With a fixed 28-unit span a random-weight model's nearly flat rows -- all 8324 logits
+// within ~2.5 units -- put hundreds of entries into the boundary bucket and every step fell back: configs[4]'s sampler 32 -> 37.6 us.)
 //   1. one pass adds every entry's fixed-point mass to its bucket (64-bit LDS atomics: integer sums, order-free);
 //   2. every wave scans the 256 buckets (4 per lane) for the first one at which the running mass reaches the target: the nucleus
 //      boundary lies in it, and everything in the buckets before it is kept;
 //   3. one pass writes that bucket's keys into the wave's 64 LDS slots; every wave bisects those <= 4 x 64 candidates for the largest
 //      key at which (mass before the bucket + mass of the candidates at or above it) reaches the target.
 // Same integers as the block-wide bisection -> same boundary key.  More than 64 candidates in a wave: the block-wide bisection.
-constexpr float SAMP_HSCALE = 256.0f / 28.0f;
+constexpr float SAMP_HSPAN = 28.0f;
 
-__device__ __forceinline__ int mass_bucket(float mx, float x) {
-    const int b = (int)((mx - x) * SAMP_HSCALE);   // v_cvt_i32_f32: NaN -> 0, +inf saturates
+__device__ __forceinline__ int mass_bucket(float mx, float x, float scale) {
+    const int b = (int)((mx - x) * scale);   // v_cvt_i32_f32: NaN -> 0, +inf saturates
     return (unsigned)b > 255u ? 255 : b;
 }
 
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
     const int top_k = pv.top_k;
     const uint64_t seed = ((uint64_t)pv.seed_hi << 32) | pv.seed_lo;
     __shared__ float redf[NW];
-    __shared__ float s_scan[NW];
+    __shared__ float s_scan[NW], s_low[NW];
     __shared__ int s_thread, s_choice;
     __shared__ float sh_tail[8];
 
@@ -412,10 +414,22 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
         }
     }
     if (top_p > 0.f && top_p < 1.f) {
-        float z = 0.f;
+        float z = 0.f, lowest = mx;   // lowest: the smallest kept logit within SAMP_HSPAN of the maximum (the histogram's span)
 #pragma unroll
         for (int j = 0; j < MAXE; ++j) z += (key[j] != 0u && key[j] >= keep_key) ? __expf(x[j] - mx) : 0.f;
+        if (!cand_cover) {   // block-uniform: only the histogram path needs the span
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j)
+                lowest = (key[j] != 0u && key[j] >= keep_key && x[j] >= mx - SAMP_HSPAN) ? fminf(lowest, x[j]) : lowest;
+            lowest = -wave_max(-lowest);
+            if ((tid & 63) == 0) s_low[tid >> 6] = lowest;   // rides on block_sum_f's barriers
+        }
         const float invZ = 1.0f / block_sum_f(z, redf);
+        if (!cand_cover) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) lowest = fminf(lowest, s_low[w]);
+        }
+        const float hscale = 255.99f / (mx - lowest);   // a one-value row: inf, every entry in bucket 0 (NaN -> 0) and the fallback below
         const unsigned long long target = (unsigned long long)((double)top_p * 1099511627776.0);
         if (cand_cover) {
             // the kept set is among the candidates every wave already holds: the nucleus boundary without a barrier per bit.  The
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
 #pragma unroll
                 for (int j = 0; j < MAXE; ++j) {
                     const unsigned long long w = ((unsigned long long)whi[j] << 20) + wlo[j];
-                    if (w != 0ull) atomicAdd(&s_hist[mass_bucket(mx, x[j])], w);
+                    if (w != 0ull) atomicAdd(&s_hist[mass_bucket(mx, x[j], hscale)], w);
                 }
                 __syncthreads();
                 unsigned long long before = 0ull;
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(SAMP_NT) void sample_kernel(const float* __restrict
                 } else {
                     uint32_t inb[MAXE];   // the keys of that bucket (0 elsewhere)
 #pragma unroll
-                    for (int j = 0; j < MAXE; ++j) inb[j] = ((whi[j] | wlo[j]) != 0u && mass_bucket(mx, x[j]) == bstar) ? key[j] : 0u;
+                    for (int j = 0; j < MAXE; ++j) inb[j] = ((whi[j] | wlo[j]) != 0u && mass_bucket(mx, x[j], hscale) == bstar) ? key[j] : 0u;
                     const int n_w = wave_publish_ge<MAXE>(inb, 1u, s_cand + (tid >> 6) * SAMP_KFAST);
                     if ((tid & 63) == 0) s_fit[tid >> 6] = n_w;
                     __syncthreads();
