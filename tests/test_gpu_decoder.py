@@ -517,6 +517,56 @@ def test_split_context_decode_attention_vs_one_workgroup_per_head_and_oracle(n_r
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geom", ["dh96_f32", "dh32_f32", "dh64_f16", "dh32_f16"])
+def test_split_context_decode_attention_other_head_sizes_and_fp16_pages(geom, tune):
+    """The split form of the decode attention at the other head sizes / page dtypes an engine can have (32, 64, 96 in fp32 -- 96 is the
+    reference's hard-coded 8 heads on a 768-wide checkpoint, the lanes-idle, non-power-of-two reduction path -- and 32, 64 over fp16
+    pages).  Two layers, ragged contexts of 3 rows that need 4 / 2 / 1 splits: the first decode steps'
+    logits against the oracle (fp32: 1e-4; fp16 pages: the storage mode's tolerance) and against the one-workgroup form, greedy ids equal."""
+    from mgea.decoder import DecoderEngine
+    from oracle.decoder_ref import DecoderRef
+    torch.set_num_threads(16)
+    dh, dt = int(geom.split("_")[0][2:]), geom.split("_")[1]
+    H, vocab, ctx = (8 if dh == 32 else 4), 600, 1024      # fp16 engines need d_model >= 256
+    C = H * dh
+    sd = synth.decoder_state_dict(29, vocab, ctx, C, 2)
+    lens_l = [1000, 300, 70]
+    T = max(lens_l)
+    idx = torch.from_numpy(synth.integers(47, "split-" + geom, (3, T), 0, vocab)).long()
+    valid = torch.arange(T)[None, :] < torch.tensor(lens_l)[:, None]
+    idx = idx * valid
+    lens = torch.tensor(lens_l, dtype=torch.int32)
+    F16_LOGIT_TOL = 4e-3       # tests/test_gpu_f16.py: the fp16 storage mode against the oracle on the fp16-rounded weights
+    if dt == "f16":
+        from mgea.decoder import F16_ROUNDED_KEYS
+        sd_ref = {k: (torch.from_numpy(np.asarray(v)).float().half().float() if k.endswith(F16_ROUNDED_KEYS) else torch.from_numpy(np.asarray(v)).float())
+                  for k, v in sd.items()}
+    else:
+        sd_ref = sd
+    ref = DecoderRef(sd_ref, H)
+    _, cache, cvalid = ref.forward(idx, None, None, valid)
+    last = idx[torch.arange(3), torch.tensor(lens_l) - 1][:, None]
+    want, _, _ = ref.forward(last, cache, cvalid, None)
+    got = []
+    for sw in (0, 64):
+        tune("attn_split", sw)
+        eng = DecoderEngine(sd, n_head=H, max_batch=4, max_ctx=ctx, dtype=dt)
+        samp = eng.sampler(1.0, 1)
+        eng.reset_and_prefill(idx, lens, want_logits=False, max_len=ctx)
+        steps = [eng.step(None, samp, want_logits=True) for _ in range(3)]
+        got.append([(i.cpu(), l.cpu()) for i, l in steps])
+        eng.close()
+    tol_ref, tol_ab = (1e-4, 2e-5) if dt == "f32" else (F16_LOGIT_TOL, F16_LOGIT_TOL)
+    err = float((got[1][0][1] - want[:, -1]).abs().max())
+    print(f"split-context decode step, {geom}: max |logit diff| vs oracle = {err:.2e}")
+    assert err < tol_ref
+    for (i0, l0), (i1, l1) in zip(got[0], got[1]):
+        assert float((l0 - l1).abs().max()) < tol_ab
+        if dt == "f32":
+            assert torch.equal(i0, i1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["ragged_4x1000", "full_8x1024", "bench_64x1024"])
 def test_f32_long_prompt_prefill_and_decode_from_its_pages_vs_oracle(shape):
     """GPTWithKV.forward returns logits for any T <= SEQ_LEN (api_cache.py:87-106), and `bench.py: extra.decoder_prefill` times the f32
