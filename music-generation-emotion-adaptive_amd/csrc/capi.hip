@@ -43,6 +43,7 @@ const TuneEntry kTune[] = {
     {TUNE_SKINNY_ONE_PER_CU, "skinny_one_per_cu", "MGEA_SKINNY_ONE_PER_CU", 0},
     {TUNE_SAMPLER_WAVE_SELECT, "sampler_wave_select", "MGEA_SAMPLER_WAVE_SELECT", 1},
     {TUNE_ATTN_SPLIT, "attn_split", "MGEA_ATTN_SPLIT", 64},
+    {TUNE_DECODER_GRAPH_STEPS, "decoder_graph_steps", "MGEA_DECODER_GRAPH_STEPS", 8},
 };
 static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];

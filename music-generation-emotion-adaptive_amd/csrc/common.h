@@ -58,6 +58,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_SKINNY_ONE_PER_CU,    // 1: skinny GEMM launches of <= 256 workgroups ask for > 80 KB of LDS, so that no two share a CU (A/B; default 0)
        TUNE_SAMPLER_WAVE_SELECT,  // 1 (default): top_k <= 64 finds its boundary wave by wave (ballots only) and merges 4 x 64 candidates after one barrier; 0: block-wide bisection, a barrier per bit
        TUNE_ATTN_SPLIT,           // the decode step's attention of at most this many (row, head) pairs spreads each pair's KV pages over several workgroups, the last one to arrive merges their partials (default 64 = 8 rows of 8 heads: measured +3..5 % tokens/s at 1-8 rows, nothing at 16, -3.5 % at 32; 0: always one workgroup per pair)
+       TUNE_DECODER_GRAPH_STEPS,  // decode steps per hipGraph launch of mgea_decoder_generate: 1, 2, 4, 8 (default) or 16; the single-step graph serves the remainder (round 4: 289.4 -> 287.6 us per step at B = 64, 168.3 -> 163.4 at B = 1)
        TUNE_COUNT };
 int tune(int key);
 

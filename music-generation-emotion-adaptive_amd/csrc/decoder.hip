@@ -104,7 +104,7 @@ struct mgea_decoder {
     // Captured decode-step graphs, one per (batch, greedy | sampled).  Everything a step reads besides its structure
     // lives in device memory (per-row state, page table, and the sampler's scalars in samp_dev), so a request with a
     // new seed / temperature / top-k / top-p / EOS id replays an existing graph: no capture, no instantiate.
-    struct GraphEntry { int batch; bool greedy; hipGraph_t graph; hipGraphExec_t exec; int64_t nodes; uint64_t last_use; };
+    struct GraphEntry { int batch; bool greedy; int steps; hipGraph_t graph; hipGraphExec_t exec; int64_t nodes; uint64_t last_use; };
     std::vector<GraphEntry> graphs;
     uint64_t use_clock = 0;
     SamplerParams* samp_dev = nullptr;
@@ -532,13 +532,15 @@ int prime_gen(mgea_decoder* h, int B, hipStream_t st) {
 
 // The captured decode step for (B, greedy): from the cache, or captured + instantiated now (least recently used
 // entry evicted beyond MAX_GRAPHS).
-constexpr size_t MAX_GRAPHS = 8;
-int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_t st, hipGraphExec_t* out) {
+constexpr size_t MAX_GRAPHS = 16;   // two per (batch, greedy | sampled): the single step and the 8-step graph
+// steps > 1: that many consecutive decode steps in one graph (switch decoder_graph_steps; the per-step state is in device memory, so the
+// steps of a graph are as independent of the host as the graphs are of each other)
+int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_t st, hipGraphExec_t* out, int steps = 1) {
     const bool greedy = sc.top_k == 1;
     for (auto& g : h->graphs)
-        if (g.batch == B && g.greedy == greedy) {
+        if (g.batch == B && g.greedy == greedy && g.steps == steps) {
             g.last_use = ++h->use_clock;
-            h->counters[0] = g.nodes;
+            if (steps == 1) h->counters[0] = g.nodes;
             *out = g.exec;
             return MGEA_OK;
         }
@@ -552,7 +554,8 @@ int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_
         h->graphs.erase(h->graphs.begin() + (long)lru);
     }
     MGEA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_gen_step(h, B, sc, st);
+    int rc = MGEA_OK;
+    for (int k = 0; k < steps && rc == MGEA_OK; ++k) rc = enqueue_gen_step(h, B, sc, st);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != MGEA_OK) {
@@ -568,8 +571,8 @@ int step_graph(mgea_decoder* h, int B, const mgea_sampler_config& sc, hipStream_
     }
     size_t nn = 0;
     (void)hipGraphGetNodes(g, nullptr, &nn);
-    h->graphs.push_back({B, greedy, g, ex, (int64_t)nn, ++h->use_clock});
-    h->counters[0] = (int64_t)nn;
+    h->graphs.push_back({B, greedy, steps, g, ex, (int64_t)nn, ++h->use_clock});
+    if (steps == 1) h->counters[0] = (int64_t)nn;
     h->counters[2] += 1;   // lifetime captures + instantiations
     h->counters[4] = (int64_t)h->graphs.size();
     *out = ex;
@@ -1040,24 +1043,34 @@ int mgea_decoder_generate(mgea_decoder* h, const int32_t* prompt_ids_dev, const 
     // the request's sampler scalars -> device memory (stream-ordered), then the cached step graph of this batch size:
     // all per-step state lives in device memory, so one graph serves every step of every request
     MGEA_TRY(launch_set_sampler_params(h->samp_dev, *s, st));
-    hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec = nullptr, gexec_k = nullptr;
     if (!h->no_graph) MGEA_TRY(step_graph(h, B, *s, st, &gexec));
+    // several steps per graph launch (switch decoder_graph_steps, a divisor of 16 so that the EOS poll below keeps its rhythm)
+    int K = h->no_graph || h->prof_stride > 0 ? 1 : tune(TUNE_DECODER_GRAPH_STEPS);
+    if (K != 2 && K != 4 && K != 8 && K != 16) K = 1;
+    if (K > 1 && n_steps >= K) MGEA_TRY(step_graph(h, B, *s, st, &gexec_k, K));
     MGEA_TRY(prime_gen(h, B, st));   // x <- embedding of the re-fed last prompt token (api_cache.py:167)
     int launched = 0;
     int32_t host_done = 0;
-    for (int i = 0; i < n_steps; ++i) {
+    while (launched < n_steps) {
+        const int i = launched;
         if (h->prof_stride > 0 && (i % h->prof_stride) == h->prof_stride / 2) {
             h->prof_now = true;  // this step runs eagerly with HIP events around every launch
             const int rc = enqueue_gen_step(h, B, *s, st);
             h->prof_now = false;
             MGEA_TRY(rc);
+            ++launched;
         } else if (h->no_graph) {
             MGEA_TRY(enqueue_gen_step(h, B, *s, st));
+            ++launched;
+        } else if (gexec_k && i % K == 0 && i + K <= n_steps) {
+            MGEA_CHECK_HIP(hipGraphLaunch(gexec_k, st));
+            launched += K;
         } else {
             MGEA_CHECK_HIP(hipGraphLaunch(gexec, st));
+            ++launched;
         }
-        ++launched;
-        if (s->eos_id >= 0 && (i % 16) == 15) {  // stop once every row has drawn EOS (api_cache.py:181)
+        if (s->eos_id >= 0 && (launched % 16) == 0) {  // stop once every row has drawn EOS (api_cache.py:181)
             MGEA_CHECK_HIP(hipMemcpyAsync(&host_done, h->n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             MGEA_CHECK_HIP(hipStreamSynchronize(st));
             if (host_done >= B) break;

@@ -158,8 +158,9 @@ def test_topk_sampling_stays_in_topk(golden):
 
 def test_one_graph_serves_every_request(golden):
     """The reference's endpoint draws a fresh seed per request (api_cache.py:204, top_k = 50): the sampler's scalars live
-    in device memory, so new seeds / temperatures / top-k / top-p / EOS ids replay the SAME captured step graph.  Only a
-    new batch size or greedy <-> sampled captures again, and going back to a known shape does not."""
+    in device memory, so new seeds / temperatures / top-k / top-p / EOS ids replay the SAME captured step graphs (one step, and
+    eight steps per launch: switch decoder_graph_steps).  Only a new batch size or greedy <-> sampled captures again, and going back
+    to a known shape does not."""
     g = golden("decoder_tiny8h")
     eng, _, _ = make(g)
     prompts = prompts_of(g)[:1]
@@ -172,10 +173,13 @@ def test_one_graph_serves_every_request(golden):
     assert eng.stats()["graph_instantiates"] == n0, "a new seed / sampler setting re-instantiated the step graph"
     assert torch.equal(a, a2) and not torch.equal(a, b)
     assert int(c.max()) < eng.vocab
-    eng.generate(prompts, 12, top_k=1)                         # greedy: a second graph
+    from mgea import _lib
+    per = 2 if _lib.tune_get("decoder_graph_steps") > 1 else 1  # a shape's single-step graph and (12 steps >= 8) its 8-steps-per-launch graph
+    assert n0 == per
+    eng.generate(prompts, 12, top_k=1)                         # greedy: a second shape
     eng.generate(prompts_of(g)[:2], 12, top_k=50, seed=1)      # other batch size: a third
     n1 = eng.stats()["graph_instantiates"]
-    assert n1 == n0 + 2 and eng.stats()["graphs_cached"] == 3
+    assert n1 == n0 + 2 * per and eng.stats()["graphs_cached"] == 3 * per
     eng.generate(prompts, 12, temperature=1.0, top_k=50, seed=11)
     eng.generate(prompts, 12, top_k=1)
     assert eng.stats()["graph_instantiates"] == n1

@@ -9,7 +9,7 @@ from mgea import _lib, synth
 from mgea.decoder import DecoderEngine
 name = sys.argv[1]
 vals = [int(v) for v in sys.argv[2:]] or [0, 1]
-B, Tp, TL = 64, 5, 1024
+B, Tp, TL = int(os.environ.get("STEP_AB_B", 64)), 5, 1024      # STEP_AB_B=1: the single-stream case
 sd = synth.decoder_state_dict(0, 8324, 1024, 512, 6)
 prompts = torch.from_numpy(synth.integers(1, "prompts", (B, Tp), 0, 8324)).to(torch.int32).cuda()
 old = _lib.tune_get(name)
