@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
 
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh % H;
+    const int arith_b = pool.arith_batch;   // > 0: physical page = logical page * arith_b + row (no table load in front of the K | V loads)
     const int t = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(const float* __restrict
     // (one operand tile) streaming at all times.  K/V are read once per step: non-temporal loads.
     f32x4 kk[NCH], vv[NVI];   // raw 16-byte groups: 4 floats or 8 halves
     auto page_base = [&](int pg, int isv) {
-        const int phys = page_table[b * max_pages + pg];
+        const int phys = arith_b > 0 ? pg * arith_b + b : page_table[b * max_pages + pg];
         return lbase + ((int64_t)(phys * 2 + isv) * H + h) * pf * EB;
     };
     auto ldraw = [](const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); };
@@ -262,12 +263,14 @@ int launch_attn_paged(const float* qkv, const KvPool& pool, int layer, const int
     MGEA_REQUIRE(H * dh == C, MGEA_EINVAL, "attention: n_head*head_dim != d_model");
     MGEA_REQUIRE(T <= 65535, MGEA_EINVAL, "attention: too many new tokens per row (%d)", T);
     const float scale = 1.0f / sqrtf((float)dh);
+    KvPool pool_k = pool;
+    if (!tune(TUNE_ATTN_ARITH_PAGES)) pool_k.arith_batch = 0;
     const int ns = split && split->part && split->count ? attn_split_count(B, H, T, max_pages) : 1;
     MGEA_REQUIRE(ns == 1 || (ns <= split->max_split && B * H * T <= split->max_items), MGEA_EINVAL, "attention: split scratch too small");
     dim3 grid(B * H, T, ns);
     const AttnSplit sp = split ? *split : AttnSplit{};
-#define MGEA_ATTN(DH, F) do { if (ns > 1) hipLaunchKernelGGL((attn_paged_kernel<DH, F, true>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); \
-                              else hipLaunchKernelGGL((attn_paged_kernel<DH, F, false>), grid, dim3(256), 0, st, qkv, pool, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); } while (0)
+#define MGEA_ATTN(DH, F) do { if (ns > 1) hipLaunchKernelGGL((attn_paged_kernel<DH, F, true>), grid, dim3(256), 0, st, qkv, pool_k, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); \
+                              else hipLaunchKernelGGL((attn_paged_kernel<DH, F, false>), grid, dim3(256), 0, st, qkv, pool_k, layer, page_table, max_pages, ctx_len, lens, out, H, T, C, scale, tiled_out, sp); } while (0)
     if (pool.f16) {
         switch (dh) {
             case 32: MGEA_ATTN(32, true); break;

@@ -44,6 +44,7 @@ const TuneEntry kTune[] = {
     {TUNE_SAMPLER_WAVE_SELECT, "sampler_wave_select", "MGEA_SAMPLER_WAVE_SELECT", 1},
     {TUNE_ATTN_SPLIT, "attn_split", "MGEA_ATTN_SPLIT", 64},
     {TUNE_DECODER_GRAPH_STEPS, "decoder_graph_steps", "MGEA_DECODER_GRAPH_STEPS", 8},
+    {TUNE_ATTN_ARITH_PAGES, "attn_arith_pages", "MGEA_ATTN_ARITH_PAGES", 1},
 };
 static_assert(sizeof(kTune) / sizeof(kTune[0]) == TUNE_COUNT, "one table row per switch");
 std::atomic<int> g_tune[TUNE_COUNT];

@@ -59,6 +59,7 @@ enum { TUNE_BF16_GEMM_TILE = 0,   // 0 = the launcher's choice; 1 128x128 / 2 25
        TUNE_SAMPLER_WAVE_SELECT,  // 1 (default): top_k <= 64 finds its boundary wave by wave (ballots only) and merges 4 x 64 candidates after one barrier; 0: block-wide bisection, a barrier per bit
        TUNE_ATTN_SPLIT,           // the decode step's attention of at most this many (row, head) pairs spreads each pair's KV pages over several workgroups, the last one to arrive merges their partials (default 64 = 8 rows of 8 heads: measured +3..5 % tokens/s at 1-8 rows, nothing at 16, -3.5 % at 32; 0: always one workgroup per pair)
        TUNE_DECODER_GRAPH_STEPS,  // decode steps per hipGraph launch of mgea_decoder_generate: 1, 2, 4, 8 (default) or 16; the single-step graph serves the remainder (round 4: 289.4 -> 287.6 us per step at B = 64, 168.3 -> 163.4 at B = 1)
+       TUNE_ATTN_ARITH_PAGES,     // 1 (default): the decode attention computes physical page ids (j * batch + b, the decoder's own allocation) instead of loading them from the page table -- one dependent scalar load less per page; 0: always the table
        TUNE_COUNT };
 int tune(int key);
 
@@ -144,6 +145,8 @@ struct KvPool {
     int32_t H, dh;
     int64_t layer_stride; // elements
     int32_t f16;          // 0: float elements, 1: _Float16 elements
+    int32_t arith_batch;  // > 0: the page table holds logical page j of row b -> physical j * arith_batch + b (what mgea_decoder_reset
+                          // writes): a kernel may compute that instead of loading it; 0: only the table says
     __host__ __device__ int64_t page_elems() const { return (int64_t)MGEA_KV_PAGE_TOKENS * dh; }
     __host__ __device__ int elt_bytes() const { return f16 ? 2 : 4; }
 };

@@ -735,6 +735,7 @@ int do_reset(mgea_decoder* h, int B, int max_len, hipStream_t st) {
     std::vector<int32_t> pt((size_t)c.max_batch * h->max_pages, 0);
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < ppr; ++j) pt[(size_t)b * h->max_pages + j] = j * B + b;
+    h->kv.arith_batch = B;   // the rule above, for kernels that would rather compute a page id than load it (attn_paged.hip)
     MGEA_CHECK_HIP(hipMemcpyAsync(h->page_table, pt.data(), pt.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     MGEA_CHECK_HIP(hipStreamSynchronize(st));  // pt is a stack-lifetime host buffer
     const size_t nb = (size_t)c.max_batch * sizeof(int32_t);
