@@ -115,6 +115,30 @@ def test_eos_stops_rows_independently(golden):
         assert (out[i, stop:] == -1).all()
 
 
+def test_steps_per_graph_launch_do_not_change_a_generation(golden, tune):
+    """mgea_decoder_generate replays several decode steps per hipGraph launch (switch decoder_graph_steps, default 8; the single-step
+    graph serves what is left over).  Whatever the value, a generation is the same: greedy ids of ragged prompts over a step count that
+    is no multiple of any of them, sampled ids for a seed, and the EOS behaviour (rows stop independently; the all-rows-done poll
+    every 16 steps ends the loop early and the rest of the output is -1)."""
+    g = golden("decoder_tiny")
+    prompts = prompts_of(g)
+    outs = []
+    for k in (1, 2, 4, 8, 16):
+        tune("decoder_graph_steps", k)
+        eng, _, _ = make(g)
+        a = eng.generate(prompts, 27, top_k=1).cpu()
+        b = eng.generate(prompts, 27, temperature=0.9, top_k=20, seed=5).cpu()
+        eos = int(a[0, 3])
+        c = eng.generate(prompts, 27, top_k=1, eos_id=eos).cpu()
+        d = eng.generate(prompts[:1], 40, top_k=1, eos_id=eos).cpu()      # its only row stops at step 4: the loop ends at the poll after 16
+        assert eng.stats()["graph_replays"] == 16 and bool((d[0, 4:] == -1).all())
+        outs.append((a, b, c, d))
+        eng.close()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert torch.equal(x, y)
+
+
 def test_twin_mode_post_ln_relu(golden):
     """generate_music/generate.py semantics (post-LN, ReLU, no cache) behind the same engine."""
     g = golden("decoder_tiny")
