@@ -15,6 +15,11 @@
 //   operands -- any k permutation is legal as long as A and W agree.
 // * Register-staged double buffering: global loads for tile t+1 are issued before the MFMAs of
 //   tile t and written to the other LDS buffer after them; one barrier per k-tile.
+// * (Round 4, measured and removed: a persistent form -- two workgroups per CU walking tile lists, the next tile's first k-tile requested
+//   under the last MFMAs and the epilogue, bitwise equal -- ran 2-9 % SLOWER than one workgroup per tile on every big shape (K = 512:
+//   0.66 vs 0.67 of the fp32 matrix peak, K = 2048: 0.75 vs 0.83), after two rounds of fighting hipcc's copies of in-flight staging
+//   registers; and a second set of staging registers (two k-tiles of loads in flight) spilled at two waves per SIMD.  The library
+//   reaches 0.83-0.94 on these shapes: profiles/r4_gemm_vendor_compare.txt.)
 // * split-K over gridDim.z writes raw partial slabs; the row epilogues (rowops.hip) sum the slabs
 //   in a fixed order, so results are run-to-run deterministic (no float atomics).
 #include "common.h"
@@ -106,15 +111,18 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 wf[n] = lds[buf][(BM + wn * WN + n * 16 + c) * 8 + ((kk * 4 + g) ^ (c & 7))];
+            // k-step outermost: consecutive MFMAs write DIFFERENT accumulators (a dependent 16x16x4 pair issues 36 clocks apart, an
+            // independent one 32: tools/micro/mfma_rate.hip).  Every accumulator still sees its k-steps in the order x, y, z, w.
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, af[m].x, acc[n][m], 0, 0, 0);
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, af[m].y, acc[n][m], 0, 0, 0);
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, af[m].z, acc[n][m], 0, 0, 0);
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, af[m].w, acc[n][m], 0, 0, 0);
-                }
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float wv = ks == 0 ? wf[n].x : ks == 1 ? wf[n].y : ks == 2 ? wf[n].z : wf[n].w;
+                        const float av = ks == 0 ? af[m].x : ks == 1 ? af[m].y : ks == 2 ? af[m].z : af[m].w;
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, acc[n][m], 0, 0, 0);
+                    }
         }
         if (t + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
