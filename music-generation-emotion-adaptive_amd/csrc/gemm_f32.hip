@@ -19,7 +19,8 @@
 //   under the last MFMAs and the epilogue, bitwise equal -- ran 2-9 % SLOWER than one workgroup per tile on every big shape (K = 512:
 //   0.66 vs 0.67 of the fp32 matrix peak, K = 2048: 0.75 vs 0.83), after two rounds of fighting hipcc's copies of in-flight staging
 //   registers; a second set of staging registers (two k-tiles of loads in flight) spilled at two waves per SIMD; a single LDS buffer
-//   with two barriers per k-tile (32 KB: three workgroups per CU) made the [64, 1024] cache fill 26.39 ms against 25.95.  The library
+//   with two barriers per k-tile (32 KB: three workgroups per CU) made the [64, 1024] cache fill 26.39 ms against 25.95; both k-halves'
+//   fragment reads requested before the first MFMA (a scheduling fence keeps them there) 26.77 ms.  The library
 //   reaches 0.83-0.94 on these shapes: profiles/r4_gemm_vendor_compare.txt.)
 // * split-K over gridDim.z writes raw partial slabs; the row epilogues (rowops.hip) sum the slabs
 //   in a fixed order, so results are run-to-run deterministic (no float atomics).
